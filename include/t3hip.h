@@ -1,0 +1,208 @@
+/*
+ * t3hip.h — C-ABI of libt3hip.so, the MI355X (gfx950) implementation of the
+ * balanced-ternary Word27 encode/decode hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer:
+ * its path is header-only C++ over std::vector.  Each entry point below names
+ * the reference function (file:line, OLD = old/include/ternary_image_codec_v6_min.hpp)
+ * whose work it performs; include/ternary_codec_v6.hpp wraps these back into the
+ * reference's own C++ names and signatures.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no C++/torch types; all structs are POD.
+ *   - "words" are the reference's Word27 ABI: 9 bytes, one GF(27) symbol (0..26) each
+ *     (OLD:666-669).  "pixels" are PixelYCbCrQuant: {u16 Yq; i16 Cbq; i16 Crq} = 6 bytes
+ *     (OLD:670-674).
+ *   - functions return T3_OK (0) or a negative T3_E_* code.  The reference's `bool`
+ *     results map to: true = T3_OK, false = T3_E_HEADER / T3_E_RS / T3_E_ARG.
+ *   - *_dev entry points take DEVICE pointers and a hipStream_t (as void*), never
+ *     allocate caller-visible memory and never synchronise unless documented.
+ *   - there is no CPU fallback: compute entry points fail with T3_E_NODEVICE when
+ *     no gfx950 device is usable.  Pure-metadata calls (plan, tables, header) are host-only.
+ */
+#ifndef T3HIP_H
+#define T3HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes --------------------------------------------------------- */
+#define T3_OK            0
+#define T3_E_NODEVICE   -1  /* no usable HIP device / t3hip_init not successful   */
+#define T3_E_HIP        -2  /* a HIP runtime call failed (see t3hip_last_hip_error) */
+#define T3_E_ARG        -3  /* bad argument (null pointer, invalid subword, k ...) */
+#define T3_E_CAPACITY   -4  /* caller's output buffer is too small                */
+#define T3_E_HEADER     -5  /* header RS / CRC-12 failure  (OLD:920,929-934 -> false) */
+#define T3_E_RS         -6  /* uncorrectable RS block      (OLD:987 -> false)     */
+
+/* ---- profile ids (OLD:34) -------------------------------------------------- */
+#define T3_P1_RS26_24     0
+#define T3_P2_RS26_22     1
+#define T3_P3_RS26_20     2
+#define T3_P4_RS26_18     3
+#define T3_P5_RS26_22_2D  4
+#define T3_RAW_MODE       0xFF
+
+/* Arithmetic/framing flavour.
+ * COMPAT: byte-exact with the reference (its non-RS "parity" map OLD:517-535, Forney
+ *         with `add` OLD:658, its encoder/decoder framings as they are).
+ * FIXED : true systematic RS consistent with the decoder's root convention, Forney
+ *         with `sub`, self-consistent v6c framing so that
+ *         decode(encode(x)) == x and <= t symbol errors per block are corrected. */
+#define T3_MODE_COMPAT 0
+#define T3_MODE_FIXED  1
+
+/* POD mirror of EncoderConfig (OLD:862-873) / DecoderConfigSeen (OLD:874-884). */
+typedef struct t3_cfg {
+    uint8_t  profile;            /* ProfileID value; T3_RAW_MODE = 0xFF          */
+    uint8_t  band_profile[9];    /* UEPLayout::band_profile (OLD:60-63), used %4  */
+    uint16_t tile_w, tile_h;     /* Tile2D (OLD:73-76)                            */
+    uint32_t seed_a, seed_b, seed_s0;      /* ScramblerSeed (OLD:77-80)           */
+    uint32_t beacon_words_period;          /* SparseBeaconCfg (OLD:95-100)        */
+    uint8_t  beacon_band_slot;
+    uint8_t  beacon_enabled;
+    uint8_t  subword;            /* SubwordMode value 27/24/21/18/15 (OLD:117)    */
+    uint8_t  centered;
+    uint32_t superframe_words;   /* EncoderConfig::superframe_words (OLD:869)     */
+    uint8_t  coset;              /* CosetID (OLD:114)                             */
+    uint8_t  mode;               /* T3_MODE_COMPAT / T3_MODE_FIXED (build-side)   */
+    uint8_t  reserved[2];
+} t3_cfg;
+
+/* Closed-form stream layout of one encode_profile_from_raw call (OLD:1043-1169). */
+typedef struct t3_layout {
+    uint64_t n_raw_words;        /* input Word27 count                            */
+    uint64_t n_sym;              /* regrouped symbols = ceil(26*W/3)  (OLD:1051-1082) */
+    uint64_t band_len[9];        /* symbols per band (i%9 split, OLD:1087-1088)   */
+    uint64_t band_blocks[9];     /* RS blocks per band (tail dropped in COMPAT, OLD:1107) */
+    uint64_t band_body_off[9];   /* first body symbol of each band (band-serial)  */
+    uint64_t body_syms;          /* 26 * sum(band_blocks)                         */
+    uint64_t body_syms_framed;   /* after beacon insertion (OLD:1118-1141)        */
+    uint64_t out_syms;           /* header + framed body                          */
+    uint64_t out_words;          /* ceil(out_syms/9) (OLD:1164)                   */
+    uint32_t header_syms;        /* 52 in COMPAT (OLD:1159-1162), 81 in FIXED     */
+    uint8_t  band_k[9];          /* RS k of each band (OLD:1089-1100)             */
+    uint8_t  interleave2d;       /* 1 if P5 && tile.w && tile.h (OLD:1083)        */
+    uint8_t  beacon_on;          /* 1 if beacon.enabled && period>0 (OLD:1118)    */
+    uint8_t  pad_;
+} t3_layout;
+
+/* Fixed-size per-frame index record; the multi-GPU exchange step all-gathers these
+ * (T3V frame index io_t3p_t3v.cpp:252-289). 96 bytes. */
+typedef struct t3_frame_record {
+    uint64_t frame_idx;
+    uint64_t n_words;            /* coded Word27 count of the frame               */
+    uint64_t byte_offset;        /* filled by t3hip_index_assemble (prefix sum)   */
+    uint32_t crc32;              /* CRC-32 (poly 0xEDB88320) of the 9*n_words payload bytes */
+    uint32_t sym_sum;            /* sum of all payload symbol bytes mod 2^32      */
+    uint8_t  header_syms[54];    /* first 6 coded words (superframe header)       */
+    uint8_t  profile;
+    uint8_t  mode;
+    uint8_t  pad_[8];
+} t3_frame_record;
+
+/* ---- lifecycle --------------------------------------------------------------- */
+int         t3hip_device_count(void);
+int         t3hip_init(int device);              /* binds the calling process to one GPU */
+int         t3hip_shutdown(void);
+int         t3hip_is_ready(void);                /* 1 after a successful t3hip_init      */
+const char* t3hip_strerror(int code);
+const char* t3hip_last_hip_error(void);
+const char* t3hip_version(void);
+
+/* ---- host-only metadata (no device needed) ------------------------------------ */
+void t3hip_cfg_default(t3_cfg* cfg);                         /* EncoderContext() defaults OLD:862-873,898 */
+int  t3hip_plan(uint64_t n_raw_words, const t3_cfg* cfg, t3_layout* out);
+uint64_t t3hip_encoded_words(uint64_t n_raw_words, const t3_cfg* cfg);   /* 0 on bad cfg */
+/* GF27Context::init tables (OLD:436-466): exp[78], log[27], mul[729], inv[27]. */
+int  t3hip_gf27_tables(uint8_t* exp78, int16_t* log27, uint8_t* mul729, uint8_t* inv27);
+/* RSCodec::build_gen (OLD:501-516): g[0..r], r = 26-k. */
+int  t3hip_rs_generator(int k, uint8_t* g_out);
+/* parity = data * P, P is k x (26-k) row-major (row i = parity of unit vector e_i). */
+int  t3hip_rs_parity_matrix(int k, int mode, uint8_t* P_out);
+/* HeaderCodec::pack / check / unpack (OLD:206-380). */
+int  t3hip_header_pack(const t3_cfg* cfg, uint32_t frame_seq, uint32_t band_map_hash, uint8_t syms27[27]);
+int  t3hip_header_check(const uint8_t syms27[27]);           /* 1 ok, 0 bad */
+int  t3hip_header_unpack(const uint8_t syms27[27], t3_cfg* out, uint32_t* frame_seq, uint32_t* band_map_hash);
+/* The coded header symbols the encoder emits in front of the body (52 / 81). */
+int  t3hip_header_encode(const t3_cfg* cfg, uint64_t n_raw_words, uint8_t* syms_out, uint32_t* n_syms);
+
+/* ---- host-buffer entry points (what the std::vector API binds) ----------------- */
+/* encode_raw_pixels_to_words OLD:723-734; words9 must hold (n_px+1)/2 words. */
+int t3hip_pack_pixels(const void* px6, uint64_t n_px, void* words9);
+/* decode_raw_words_to_pixels OLD:735-747; px6 must hold 2*n_words pixels. */
+int t3hip_unpack_words(const void* words9, uint64_t n_words, void* px6);
+/* encode_profile_from_raw OLD:1043-1169. */
+int t3hip_encode_profile(const void* raw9, uint64_t n_raw, const t3_cfg* cfg,
+                         void* out9, uint64_t cap_words, uint64_t* n_out);
+/* decode_profile_to_raw OLD:995-1041.  `seen` is DecoderContext::cfg_last_seen: read for the
+ * RAW shortcut, overwritten from the header once it decodes (OLD:1006-1013) — also when a
+ * later RS block fails, as in the reference. */
+int t3hip_decode_profile(const void* in9, uint64_t n_in, t3_cfg* seen,
+                         void* out9, uint64_t cap_words, uint64_t* n_out);
+/* Build-side conveniences named by the north star: pixels -> coded words in one fused
+ * launch (= OLD:723 + OLD:1043), coded words -> pixels (= OLD:995 + OLD:735). */
+int t3hip_encode_frame(const void* px6, uint64_t n_px, const t3_cfg* cfg,
+                       void* out9, uint64_t cap_words, uint64_t* n_out);
+int t3hip_decode_frame(const void* in9, uint64_t n_in, t3_cfg* seen,
+                       void* px6, uint64_t cap_px, uint64_t* n_px);
+
+/* ---- device-resident entry points (async on `stream` unless noted) ---------------- */
+int t3hip_pack_pixels_dev(const void* d_px6, uint64_t n_px, void* d_words9, void* stream);
+int t3hip_unpack_words_dev(const void* d_words9, uint64_t n_words, void* d_px6, void* stream);
+int t3hip_encode_profile_dev(const void* d_raw9, uint64_t n_raw, const t3_cfg* cfg,
+                             void* d_out9, uint64_t cap_words, uint64_t* n_out, void* stream);
+int t3hip_encode_frame_dev(const void* d_px6, uint64_t n_px, const t3_cfg* cfg,
+                           void* d_out9, uint64_t cap_words, uint64_t* n_out, void* stream);
+/* Decode with the header parsed on the host: copies the 6 (COMPAT) / 9 (FIXED) header words
+ * device->host and synchronises `stream` once, launches the body kernels, then synchronises
+ * again to read the block-failure flag.  `to_pixels` selects Word27 or pixel output. */
+int t3hip_decode_profile_dev(const void* d_in9, uint64_t n_in, t3_cfg* seen,
+                             void* d_out, uint64_t cap_units, uint64_t* n_out,
+                             int to_pixels, void* stream);
+/* Fully asynchronous body decode for a caller that already knows the stream's config
+ * (e.g. from t3hip_read_header_dev): no synchronisation; *d_fail (device u32) is
+ * incremented for every uncorrectable block. */
+int t3hip_read_header_dev(const void* d_in9, uint64_t n_in, int mode, t3_cfg* out_cfg,
+                          uint64_t* n_raw_words, void* stream);            /* synchronises */
+int t3hip_decode_body_dev(const void* d_in9, uint64_t n_in, const t3_cfg* cfg, uint64_t n_raw_words,
+                          void* d_out, uint64_t cap_units, uint64_t* n_out, int to_pixels,
+                          uint32_t* d_fail, void* stream);
+
+/* ---- block-level RS(26,k) (RSCodec::encode_block OLD:517-535, decode_block OLD:546-662) */
+int t3hip_rs_encode_blocks_dev(int k, int mode, const uint8_t* d_data_k, uint64_t n_blocks,
+                               uint8_t* d_code26, void* stream);
+/* d_code26 is corrected in place (inout_n), d_data_k receives the first k symbols (out_k),
+ * d_ok[b] = 1/0 is decode_block's return value.  On a 0 the reference leaves inout_n
+ * partially modified and out_k untouched; so does this. */
+int t3hip_rs_decode_blocks_dev(int k, int mode, uint8_t* d_code26, uint64_t n_blocks,
+                               uint8_t* d_data_k, uint8_t* d_ok, void* stream);
+
+/* ---- trit error injector for the recovery test ------------------ */
+/* For every 26-symbol block of the body region [first_sym, first_sym+26*n_blocks): a counter hash of
+ * (seed, block) picks e in 0..max_err distinct positions and alters one trit of each. */
+int t3hip_inject_errors_dev(void* d_words9, uint64_t first_sym, uint64_t n_blocks,
+                            uint32_t seed, int max_err, void* stream);
+
+/* ---- frame index record (multi-GPU exchange payload) -------------------------------- */
+int t3hip_frame_record_dev(const void* d_words9, uint64_t n_words, uint64_t frame_idx,
+                           const t3_cfg* cfg, t3_frame_record* d_rec, void* d_scratch,
+                           uint64_t scratch_bytes, void* stream);
+uint64_t t3hip_frame_record_scratch_bytes(uint64_t n_words);
+/* Host: sort gathered records by frame_idx and fill byte_offset (T3V index, io_t3p_t3v.cpp:252-289). */
+int t3hip_index_assemble(t3_frame_record* recs, uint64_t n_recs, uint64_t first_payload_offset);
+
+/* ---- timing helper: HIP events on the caller's stream -------------------------------- */
+int t3hip_event_create(void** ev);
+int t3hip_event_record(void* ev, void* stream);
+int t3hip_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on stop */
+int t3hip_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T3HIP_H */
