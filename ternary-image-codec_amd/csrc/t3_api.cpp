@@ -1,0 +1,375 @@
+// t3_api.cpp — the C-ABI of libt3hip.so (include/t3hip.h): context, tile planning, kernel launches.
+// Host logic only; all arithmetic on the data path happens in t3_kernels.hip / t3_decode.hip.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/t3hip.h"
+#include "t3_host.hpp"
+#include "t3_kernels.h"
+#include "t3_decode.h"
+
+using namespace t3;
+
+namespace {
+
+struct LutImage { uint32_t* d_img = nullptr; uint32_t bytes = 0; uint32_t k_off[4] = {0, 0, 0, 0}; };
+
+struct Ctx {
+    int dev = -1; bool ready = false; int n_cu = 256;
+    hipStream_t stream = nullptr;                       // used by the host-buffer entry points
+    RsTables* d_tab = nullptr;
+    uint8_t* d_P[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    std::map<uint32_t, LutImage> luts;                  // key = kmask | mode << 8
+    void* buf[4] = {nullptr, nullptr, nullptr, nullptr}; size_t cap[4] = {0, 0, 0, 0};   // grow-only device scratch
+    uint32_t* d_flag = nullptr;                         // failure counter for the synchronous decode entry points
+    std::string hip_err;
+    std::mutex mu;
+};
+Ctx g;
+
+int fail_hip(hipError_t e, const char* what) { g.hip_err = std::string(what) + ": " + hipGetErrorString(e); return T3_E_HIP; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail_hip(e_, #x); } while (0)
+
+int k_index(int k) { return k == 24 ? 0 : k == 22 ? 1 : k == 20 ? 2 : k == 18 ? 3 : -1; }
+const int kOfIndex[4] = {24, 22, 20, 18};
+
+int scratch(int slot, size_t bytes, void** out) {
+    if (bytes > g.cap[slot]) {
+        if (g.buf[slot]) HIPCHK(hipFree(g.buf[slot]));
+        g.buf[slot] = nullptr; g.cap[slot] = 0;
+        const size_t want = bytes + bytes / 8 + 4096;
+        HIPCHK(hipMalloc(&g.buf[slot], want));
+        g.cap[slot] = want;
+    }
+    *out = g.buf[slot];
+    return T3_OK;
+}
+
+int get_lut(uint32_t kmask, int mode, const LutImage** out) {
+    const uint32_t key = kmask | (uint32_t)mode << 8;
+    auto it = g.luts.find(key);
+    if (it == g.luts.end()) {
+        LutImage L; std::vector<uint32_t> all;
+        for (int i = 0; i < 4; ++i) if (kmask >> i & 1) {
+            std::vector<uint32_t> img; build_encode_lut(kOfIndex[i], mode, img);
+            L.k_off[i] = (uint32_t)all.size() * 4u;
+            all.insert(all.end(), img.begin(), img.end());
+        }
+        L.bytes = (uint32_t)all.size() * 4u;
+        HIPCHK(hipMalloc((void**)&L.d_img, L.bytes ? L.bytes : 16));
+        HIPCHK(hipMemcpy(L.d_img, all.data(), L.bytes, hipMemcpyHostToDevice));
+        it = g.luts.emplace(key, L).first;
+    }
+    *out = &it->second;
+    return T3_OK;
+}
+
+DevDiv to_dev(FastDiv f) { return DevDiv{f.mul, f.sh, f.d}; }
+uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
+uint64_t gcd64(uint64_t a, uint64_t b) { while (b) { uint64_t t = a % b; a = b; b = t; } return a; }
+
+// ------------------------------------------------------------------------------------------------
+// K2 launch planning: one launch covers a set of bands whose k's have a manageable lcm
+// ------------------------------------------------------------------------------------------------
+struct EncLaunch { EncArgs a; uint32_t grid, block; };
+
+bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, int fe, const LutImage& lut, EncLaunch& out) {
+    EncArgs& a = out.a; memset(&a, 0, sizeof a);
+    const uint32_t GS = fe == FE_PIXELS ? kGroupSyms : kGroupSymsW, GB = fe == FE_PIXELS ? 72u : 108u;
+    uint64_t Lk = 2;
+    for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) Lk = Lk / gcd64(Lk, L.band_k[b]) * L.band_k[b];
+    uint32_t lut_bytes = lut.bytes;
+    // pick q (even): tile = 9*Lk*q stream symbols; band b then owns Lk*q/k_b blocks = that/2 lane pairs
+    double best_score = -1; uint32_t best_q = 0;
+    for (int pass = 0; pass < 2 && !best_q; ++pass) {
+        const uint32_t budget = pass == 0 ? 80u * 1024u : 160u * 1024u;
+        for (uint32_t q = 2; q <= 4096; q += 2) {
+            const uint64_t Lq = Lk * q; if (9 * Lq > 60000) break;
+            uint32_t waves = 0, pairs_total = 0, outb = 0;
+            for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) {
+                const uint32_t nb = (uint32_t)(Lq / L.band_k[b]), pairs = nb / 2;
+                waves += (pairs + 63) / 64; pairs_total += pairs; outb += round16(26 * nb + 32);
+            }
+            if (waves > (uint32_t)kMaxWaves) break;
+            const uint32_t groups = (uint32_t)(9 * Lq / GS) + 3, stage = groups * GB + 32;
+            const uint32_t total = round16(lut_bytes) + round16((uint32_t)(9 * Lq)) + 16 + std::max(round16(stage), outb);
+            if (total > budget) break;
+            const double util = (double)pairs_total / (64.0 * waves);
+            const double score = util + 1e-7 * (double)Lq;          // utilisation first, then the larger tile
+            if (score > best_score) { best_score = score; best_q = q; }
+        }
+    }
+    if (!best_q) return false;
+    const uint32_t Lq = (uint32_t)(Lk * best_q);
+    a.Lq = Lq; a.lut_bytes = round16(lut_bytes);
+    uint32_t off = a.lut_bytes;
+    a.sym_off = off; off += round16(9 * Lq) + 16;
+    a.stage_off = off;
+    a.stage_groups = 9 * Lq / GS + 3;
+    uint32_t outb = 0, nw = 0, n_tiles = 0;
+    for (int b = 0; b < 9; ++b) {
+        a.band_k[b] = L.band_k[b]; a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b];
+        a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6);
+        a.band_lut_off[b] = lut.k_off[k_index(L.band_k[b])];
+        if (!(band_mask >> b & 1)) { a.band_nb_tile[b] = 0; a.band_blocks[b] = 0; continue; }
+        const uint32_t nb = Lq / L.band_k[b], pairs = nb / 2;
+        a.band_nb_tile[b] = nb; a.band_out_off[b] = a.stage_off + outb; outb += round16(26 * nb + 32);
+        for (uint32_t w = 0; w < (pairs + 63) / 64; ++w) { a.wave_band[nw] = b; a.wave_pair0[nw] = 64 * w; ++nw; }
+        n_tiles = std::max<uint32_t>(n_tiles, (uint32_t)((L.band_blocks[b] + nb - 1) / nb));
+    }
+    a.n_waves = nw; a.n_tiles = n_tiles;
+    a.lds_bytes = a.stage_off + std::max(round16(a.stage_groups * GB + 32), outb);
+    a.n_sym = (uint32_t)L.n_sym;
+    const ScrCycle sc = scrambler_cycle(cfg.seed_a, cfg.seed_b, cfg.seed_s0);
+    a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
+    a.il_on = L.interleave2d;
+    if (a.il_on) {
+        const uint64_t A = (uint64_t)cfg.tile_w * cfg.tile_h;
+        a.il_w = cfg.tile_w; a.il_A = (uint32_t)std::min<uint64_t>(A, std::max<uint64_t>(L.n_sym, 1));
+        a.div_A = to_dev(fastdiv(a.il_A)); a.div_w = to_dev(fastdiv(a.il_w));
+    }
+    out.block = 64u * std::max<uint32_t>(nw, 4u);
+    const uint32_t by_lds = std::max<uint32_t>(1u, (160u * 1024u) / a.lds_bytes), by_waves = std::max<uint32_t>(1u, 32u / (out.block / 64u));
+    out.grid = std::max<uint32_t>(1u, std::min<uint32_t>(n_tiles, (uint32_t)g.n_cu * std::min(by_lds, by_waves)));
+    return true;
+}
+
+template <int FE> int launch_enc(const EncLaunch& e, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) { HIPCHK(hipFuncSetAttribute((const void*)encode_kernel<FE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; }
+    hipLaunchKernelGGL(encode_kernel<FE>, dim3(e.grid), dim3(e.block), e.a.lds_bytes, s, e.a);
+    HIPCHK(hipGetLastError());
+    return T3_OK;
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+// pixels|raw words (device) -> coded stream (device)
+int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, void* d_out, uint64_t cap_words, uint64_t* n_out, hipStream_t s) {
+    if (!g.ready) return T3_E_NODEVICE;
+    if (!cfg || !n_out || (n_units && !d_in) || !aligned16(d_in) || !aligned16(d_out)) return T3_E_ARG;
+    const uint64_t n_raw = fe == FE_PIXELS ? (n_units + 1) / 2 : n_units;
+    t3_layout L; int rc = plan(n_raw, *cfg, L); if (rc != T3_OK) return rc;
+    *n_out = L.out_words;
+    if (L.out_words > cap_words) return T3_E_CAPACITY;
+    if (L.out_words && !d_out) return T3_E_ARG;
+    if (cfg->profile == T3_RAW_MODE) {                                   // OLD:1046-1050: out = in
+        if (fe == FE_WORDS) { if (n_raw) HIPCHK(hipMemcpyAsync(d_out, d_in, n_raw * 9, hipMemcpyDeviceToDevice, s)); }
+        else if (n_raw) { hipLaunchKernelGGL(pack_pixels_kernel, dim3((unsigned)((n_raw + 255) / 256)), dim3(256), 0, s, (const uint16_t*)d_in, n_units, (uint8_t*)d_out, n_raw); HIPCHK(hipGetLastError()); }
+        return T3_OK;
+    }
+    std::lock_guard<std::mutex> lk(g.mu);
+    uint8_t hdr[84]; memset(hdr, 0, sizeof hdr);
+    const uint32_t hs = (uint32_t)header_encode(*cfg, n_raw, hdr);
+    const uint32_t pad = (uint32_t)(9 * L.out_words - L.out_syms);
+    uint8_t* body_out = (uint8_t*)d_out + hs; uint8_t* frame_out = (uint8_t*)d_out;
+    if (L.beacon_on) { void* p; rc = scratch(2, L.body_syms + 64, &p); if (rc) return rc; body_out = (uint8_t*)p; frame_out = nullptr; }
+    // group bands into launches: all together when the lcm of their k's keeps the tile small, else one launch per k
+    uint32_t kmask = 0; for (int b = 0; b < 9; ++b) kmask |= 1u << k_index(L.band_k[b]);
+    std::vector<uint32_t> groups;
+    {
+        const LutImage* lut; rc = get_lut(kmask, cfg->mode, &lut); if (rc) return rc;
+        EncLaunch e;
+        if (plan_enc_group(L, *cfg, 0x1FF, fe, *lut, e)) groups.push_back(0x1FF);
+        else for (int i = 0; i < 4; ++i) if (kmask >> i & 1) { uint32_t m = 0; for (int b = 0; b < 9; ++b) if (k_index(L.band_k[b]) == i) m |= 1u << b; groups.push_back(m); }
+    }
+    bool first = true;
+    for (uint32_t m : groups) {
+        uint32_t km = 0; for (int b = 0; b < 9; ++b) if (m >> b & 1) km |= 1u << k_index(L.band_k[b]);
+        const LutImage* lut; rc = get_lut(km, cfg->mode, &lut); if (rc) return rc;
+        EncLaunch e; if (!plan_enc_group(L, *cfg, m, fe, *lut, e)) return T3_E_ARG;
+        e.a.in = (const uint8_t*)d_in; e.a.n_units = n_units; e.a.n_units_pad = fe == FE_PIXELS ? 2 * n_raw : n_units;
+        e.a.body_out = body_out; e.a.frame_out = first ? frame_out : nullptr; e.a.lut_img = lut->d_img;
+        e.a.hdr_syms = hs; e.a.pad_bytes = pad; e.a.out_syms = L.out_syms; memcpy(e.a.hdr, hdr, sizeof hdr);
+        rc = fe == FE_PIXELS ? launch_enc<FE_PIXELS>(e, s) : launch_enc<FE_WORDS>(e, s);
+        if (rc) return rc;
+        first = false;
+    }
+    if (L.beacon_on) {
+        BeaconArgs b; memset(&b, 0, sizeof b);
+        b.body = body_out; b.frame_out = (uint8_t*)d_out; b.body_syms = L.body_syms; b.framed_syms = L.body_syms_framed;
+        b.period = cfg->beacon_words_period; b.slot = cfg->beacon_band_slot;
+        b.sym = beacon_symbol(cfg->profile, (uint16_t)(cfg->superframe_words % 5), 0);     // OLD:1130
+        b.hdr_syms = hs; b.pad_bytes = pad; memcpy(b.hdr, hdr, sizeof hdr);
+        const unsigned nb = (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, (L.body_syms_framed + 255) / 256), 65536);
+        hipLaunchKernelGGL(beacon_kernel, dim3(nb), dim3(256), 0, s, b);
+        HIPCHK(hipGetLastError());
+    }
+    return T3_OK;
+}
+
+// host vector -> device scratch -> kernel -> host vector
+int host_roundtrip_in(int slot, const void* h, size_t bytes, void** d) {
+    int rc = scratch(slot, bytes + 64, d); if (rc) return rc;
+    if (bytes) HIPCHK(hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, g.stream));
+    return T3_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int t3hip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+int t3hip_init(int device) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.ready && g.dev == device) return T3_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return T3_E_NODEVICE;
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t p; HIPCHK(hipGetDeviceProperties(&p, device));
+    if (std::string(p.gcnArchName).find("gfx950") == std::string::npos) { g.hip_err = std::string("not a gfx950 device: ") + p.gcnArchName; return T3_E_NODEVICE; }
+    g.n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    const Field& F = field();
+    HIPCHK(hipMalloc((void**)&g.d_tab, sizeof(RsTables)));
+    HIPCHK(hipMemcpy(g.d_tab, &F.t, sizeof(RsTables), hipMemcpyHostToDevice));
+    for (int i = 0; i < 4; ++i) for (int m = 0; m < 2; ++m) {
+        uint8_t P[24 * 8]; rs_parity_matrix(kOfIndex[i], m, P);
+        HIPCHK(hipMalloc((void**)&g.d_P[i][m], sizeof P));
+        HIPCHK(hipMemcpy(g.d_P[i][m], P, sizeof P, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMalloc((void**)&g.d_flag, 64));
+    int rc = t3::decode_init(g.d_tab); if (rc) return rc;
+    g.dev = device; g.ready = true;
+    return T3_OK;
+}
+
+int t3hip_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.ready) return T3_OK;
+    (void)hipDeviceSynchronize();
+    for (auto& kv : g.luts) (void)hipFree(kv.second.d_img);
+    g.luts.clear();
+    for (int i = 0; i < 4; ++i) { if (g.buf[i]) (void)hipFree(g.buf[i]); g.buf[i] = nullptr; g.cap[i] = 0; for (int m = 0; m < 2; ++m) { (void)hipFree(g.d_P[i][m]); g.d_P[i][m] = nullptr; } }
+    (void)hipFree(g.d_tab); (void)hipFree(g.d_flag); (void)hipStreamDestroy(g.stream);
+    g.ready = false; g.dev = -1;
+    return T3_OK;
+}
+int t3hip_is_ready(void) { return g.ready ? 1 : 0; }
+const char* t3hip_strerror(int c) {
+    switch (c) {
+        case T3_OK: return "ok"; case T3_E_NODEVICE: return "no usable gfx950 device (t3hip_init not done or failed)";
+        case T3_E_HIP: return "HIP runtime error"; case T3_E_ARG: return "bad argument"; case T3_E_CAPACITY: return "output buffer too small";
+        case T3_E_HEADER: return "superframe header did not decode (RS/CRC-12)"; case T3_E_RS: return "uncorrectable RS block";
+    }
+    return "unknown";
+}
+const char* t3hip_last_hip_error(void) { return g.hip_err.c_str(); }
+const char* t3hip_version(void) { return "t3hip 0.1 (gfx950)"; }
+
+// ---- host-only metadata ---------------------------------------------------------------------------------
+void t3hip_cfg_default(t3_cfg* c) {
+    memset(c, 0, sizeof *c);
+    c->profile = T3_P2_RS26_22; for (int b = 0; b < 9; ++b) c->band_profile[b] = 1;     // OLD:864,898
+    c->seed_a = c->seed_b = c->seed_s0 = 1; c->superframe_words = 8192; c->subword = 27; c->centered = 1;
+}
+int t3hip_plan(uint64_t n_raw, const t3_cfg* cfg, t3_layout* out) { if (!cfg || !out) return T3_E_ARG; return plan(n_raw, *cfg, *out); }
+uint64_t t3hip_encoded_words(uint64_t n_raw, const t3_cfg* cfg) { t3_layout L; if (!cfg || plan(n_raw, *cfg, L) != T3_OK) return 0; return L.out_words; }
+int t3hip_gf27_tables(uint8_t* e78, int16_t* l27, uint8_t* m729, uint8_t* i27) {
+    const Field& F = field();
+    if (e78) memcpy(e78, F.exp78, 78); if (l27) memcpy(l27, F.log, sizeof F.log);
+    if (m729) memcpy(m729, F.t.mul, 729); if (i27) memcpy(i27, F.t.inv, 27);
+    return T3_OK;
+}
+int t3hip_rs_generator(int k, uint8_t* g_out) { if (!valid_k(k) || !g_out) return T3_E_ARG; rs_generator(k, g_out); return T3_OK; }
+int t3hip_rs_parity_matrix(int k, int mode, uint8_t* P) { if (!valid_k(k) || !P || mode < 0 || mode > 1) return T3_E_ARG; rs_parity_matrix(k, mode, P); return T3_OK; }
+int t3hip_header_pack(const t3_cfg* c, uint32_t fs, uint32_t bh, uint8_t s[27]) { if (!c || !s) return T3_E_ARG; header_pack(*c, fs, bh, s); return T3_OK; }
+int t3hip_header_check(const uint8_t s[27]) { return s && header_check(s) ? 1 : 0; }
+int t3hip_header_unpack(const uint8_t s[27], t3_cfg* o, uint32_t* fs, uint32_t* bh) { if (!s || !o) return T3_E_ARG; header_unpack(s, *o, fs, bh); return T3_OK; }
+int t3hip_header_encode(const t3_cfg* c, uint64_t n_raw, uint8_t* out, uint32_t* n) {
+    if (!c || !out || !n) return T3_E_ARG;
+    t3_layout L; int rc = plan(n_raw, *c, L); if (rc) return rc;
+    if (c->profile == T3_RAW_MODE) { *n = 0; return T3_OK; }
+    *n = (uint32_t)header_encode(*c, n_raw, out); return T3_OK;
+}
+
+// ---- device-resident entry points -----------------------------------------------------------------------
+int t3hip_pack_pixels_dev(const void* d_px, uint64_t n_px, void* d_words, void* stream) {
+    if (!g.ready) return T3_E_NODEVICE;
+    const uint64_t nw = (n_px + 1) / 2; if (!nw) return T3_OK;
+    if (!d_px || !d_words) return T3_E_ARG;
+    hipLaunchKernelGGL(pack_pixels_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)d_px, n_px, (uint8_t*)d_words, nw);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+int t3hip_unpack_words_dev(const void* d_words, uint64_t n_words, void* d_px, void* stream) {
+    if (!g.ready) return T3_E_NODEVICE;
+    if (!n_words) return T3_OK;
+    if (!d_px || !d_words) return T3_E_ARG;
+    hipLaunchKernelGGL(unpack_words_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_words, n_words, (uint16_t*)d_px);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+int t3hip_encode_profile_dev(const void* d_raw, uint64_t n_raw, const t3_cfg* cfg, void* d_out, uint64_t cap, uint64_t* n_out, void* stream) {
+    return encode_dev(FE_WORDS, d_raw, n_raw, cfg, d_out, cap, n_out, (hipStream_t)stream);
+}
+int t3hip_encode_frame_dev(const void* d_px, uint64_t n_px, const t3_cfg* cfg, void* d_out, uint64_t cap, uint64_t* n_out, void* stream) {
+    return encode_dev(FE_PIXELS, d_px, n_px, cfg, d_out, cap, n_out, (hipStream_t)stream);
+}
+int t3hip_rs_encode_blocks_dev(int k, int mode, const uint8_t* d_data, uint64_t n_blocks, uint8_t* d_code, void* stream) {
+    if (!g.ready) return T3_E_NODEVICE;
+    if (!valid_k(k) || mode < 0 || mode > 1) return T3_E_ARG;
+    if (!n_blocks) return T3_OK;
+    hipLaunchKernelGGL(rs_encode_blocks_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_data, n_blocks, k, g.d_P[k_index(k)][mode], g.d_tab, d_code);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+
+// ---- host-buffer entry points ---------------------------------------------------------------------------
+int t3hip_pack_pixels(const void* px, uint64_t n_px, void* words) {
+    if (!g.ready) return T3_E_NODEVICE;
+    const uint64_t nw = (n_px + 1) / 2; if (!nw) return T3_OK;
+    if (!px || !words) return T3_E_ARG;
+    void *di, *dout; int rc;
+    { std::lock_guard<std::mutex> lk(g.mu); rc = host_roundtrip_in(0, px, n_px * 6, &di); if (rc) return rc; rc = scratch(1, nw * 9, &dout); if (rc) return rc; }
+    rc = t3hip_pack_pixels_dev(di, n_px, dout, g.stream); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(words, dout, nw * 9, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream)); return T3_OK;
+}
+int t3hip_unpack_words(const void* words, uint64_t n_words, void* px) {
+    if (!g.ready) return T3_E_NODEVICE;
+    if (!n_words) return T3_OK;
+    if (!px || !words) return T3_E_ARG;
+    void *di, *dout; int rc;
+    { std::lock_guard<std::mutex> lk(g.mu); rc = host_roundtrip_in(0, words, n_words * 9, &di); if (rc) return rc; rc = scratch(1, n_words * 12, &dout); if (rc) return rc; }
+    rc = t3hip_unpack_words_dev(di, n_words, dout, g.stream); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(px, dout, n_words * 12, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream)); return T3_OK;
+}
+static int encode_host(int fe, const void* in, uint64_t n_units, const t3_cfg* cfg, void* out, uint64_t cap, uint64_t* n_out) {
+    if (!g.ready) return T3_E_NODEVICE;
+    if (!cfg || !n_out || (n_units && !in)) return T3_E_ARG;
+    const uint64_t n_raw = fe == FE_PIXELS ? (n_units + 1) / 2 : n_units;
+    t3_layout L; int rc = plan(n_raw, *cfg, L); if (rc) return rc;
+    *n_out = L.out_words; if (L.out_words > cap) return T3_E_CAPACITY;
+    void *di, *dout;
+    { std::lock_guard<std::mutex> lk(g.mu); rc = host_roundtrip_in(0, in, n_units * (fe == FE_PIXELS ? 6 : 9), &di); if (rc) return rc; rc = scratch(1, L.out_words * 9 + 64, &dout); if (rc) return rc; }
+    rc = encode_dev(fe, di, n_units, cfg, dout, L.out_words, n_out, g.stream); if (rc) return rc;
+    if (L.out_words) HIPCHK(hipMemcpyAsync(out, dout, L.out_words * 9, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream)); return T3_OK;
+}
+int t3hip_encode_profile(const void* raw, uint64_t n_raw, const t3_cfg* cfg, void* out, uint64_t cap, uint64_t* n_out) { return encode_host(FE_WORDS, raw, n_raw, cfg, out, cap, n_out); }
+int t3hip_encode_frame(const void* px, uint64_t n_px, const t3_cfg* cfg, void* out, uint64_t cap, uint64_t* n_out) { return encode_host(FE_PIXELS, px, n_px, cfg, out, cap, n_out); }
+
+// ---- timing helper ------------------------------------------------------------------------------------------
+int t3hip_event_create(void** ev) { if (!g.ready) return T3_E_NODEVICE; hipEvent_t e; HIPCHK(hipEventCreate(&e)); *ev = e; return T3_OK; }
+int t3hip_event_record(void* ev, void* stream) { HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return T3_OK; }
+int t3hip_event_elapsed_ms(void* a, void* b, float* ms) { HIPCHK(hipEventSynchronize((hipEvent_t)b)); HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return T3_OK; }
+int t3hip_event_destroy(void* ev) { HIPCHK(hipEventDestroy((hipEvent_t)ev)); return T3_OK; }
+
+}  // extern "C"
+
+// decode-side entry points live in t3_api_decode.cpp (same library)
+namespace t3 {
+int api_ready() { return g.ready ? 1 : 0; }
+hipStream_t api_stream() { return g.stream; }
+int api_scratch(int slot, size_t bytes, void** out) { std::lock_guard<std::mutex> lk(g.mu); return scratch(slot, bytes, out); }
+int api_fail_hip(hipError_t e, const char* what) { return fail_hip(e, what); }
+uint32_t* api_flag() { return g.d_flag; }
+RsTables* api_tables() { return g.d_tab; }
+int api_n_cu() { return g.n_cu; }
+}  // namespace t3

@@ -1,0 +1,200 @@
+// t3_api_decode.cpp — decode-side half of the C-ABI (include/t3hip.h): header parse on the host, body kernels
+// on the device, block-level decode, error injector, frame index record.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/t3hip.h"
+#include "t3_decode.h"
+#include "t3_host.hpp"
+
+namespace t3 {
+int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out);
+int api_fail_hip(hipError_t e, const char* what); uint32_t* api_flag(); RsTables* api_tables(); int api_n_cu();
+}  // namespace t3
+using namespace t3;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return api_fail_hip(e_, #x); } while (0)
+
+namespace {
+uint32_t* d_zpow = nullptr;     // CRC "append 2^j zero bytes" operators
+uint32_t* d_crc_acc = nullptr;  // [0] xor accumulator, [1] symbol sum
+
+DevDiv to_dev(FastDiv f) { return DevDiv{f.mul, f.sh, f.d}; }
+unsigned grid_for(uint64_t items, unsigned block) { return (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, (items + block - 1) / block), 1u << 20); }
+
+// body decode with a known config (header already parsed)
+int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_raw, const uint8_t next[3],
+                void* d_out, uint64_t cap_units, uint64_t* n_out, int to_pixels, uint32_t* d_fail, hipStream_t s) {
+    const bool fixed = cfg.mode == T3_MODE_FIXED;
+    DecArgs a; memset(&a, 0, sizeof a);
+    EmitArgs e; memset(&e, 0, sizeof e);
+    a.in = (const uint8_t*)d_in; a.fail = d_fail; a.tab = api_tables(); a.fixed = fixed ? 1 : 0;
+    const ScrCycle sc = scrambler_cycle_from_next(next, cfg.seed_s0);
+    a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
+    a.beacon_on = (cfg.beacon_enabled && cfg.beacon_words_period > 0) ? 1 : 0; a.period = cfg.beacon_words_period; a.slot = cfg.beacon_band_slot;
+    uint64_t use_syms, n_words, total = 0;
+    if (!fixed) {
+        DecLayoutCompat D; plan_decode_compat(n_in, cfg, D);
+        a.hdr_syms = 54;
+        for (int b = 0; b < 9; ++b) { a.band_k[b] = D.band_k[b]; a.band_blocks[b] = D.band_blocks[b]; a.band_first[b] = total; a.band_off[b] = D.use_off[b]; total += D.band_blocks[b]; }
+        use_syms = D.use_syms; n_words = D.out_words;
+    } else {
+        t3_layout L; int rc = plan(n_raw, cfg, L); if (rc) return T3_E_HEADER;
+        if (L.out_words > n_in) return T3_E_HEADER;                      // truncated stream
+        a.hdr_syms = 81; a.n_sym = L.n_sym;
+        for (int b = 0; b < 9; ++b) { a.band_k[b] = L.band_k[b]; a.band_blocks[b] = L.band_blocks[b]; a.band_first[b] = total; a.band_off[b] = L.band_body_off[b]; total += L.band_blocks[b]; }
+        use_syms = L.n_sym; n_words = n_raw;
+    }
+    a.total_blocks = total;
+    const uint64_t units = to_pixels ? 2 * n_words : n_words;
+    *n_out = units;
+    if (units > cap_units) return T3_E_CAPACITY;
+    void* d_use; int rc = api_scratch(3, use_syms + 64, &d_use); if (rc) return rc;
+    a.use = (uint8_t*)d_use;
+    if (total) { hipLaunchKernelGGL(dec_gather_rs_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, a); HIPCHK(hipGetLastError()); }
+    e.use = (const uint8_t*)d_use; e.use_syms = use_syms; e.out = d_out; e.n_words = n_words; e.to_pixels = to_pixels ? 1 : 0;
+    const bool il = cfg.profile == T3_P5_RS26_22_2D && cfg.tile_w && cfg.tile_h && use_syms;   // OLD:1018
+    e.il_on = il ? 1 : 0;
+    if (il) {
+        const uint64_t A = (uint64_t)cfg.tile_w * cfg.tile_h;
+        e.il_w = cfg.tile_w; e.il_A = (uint32_t)std::min<uint64_t>(A, use_syms);
+        e.div_A = to_dev(fastdiv(e.il_A)); e.div_w = to_dev(fastdiv(e.il_w));
+    }
+    if (n_words) { hipLaunchKernelGGL(dec_emit_kernel, dim3(grid_for(n_words, 256)), dim3(256), 0, s, e); HIPCHK(hipGetLastError()); }
+    return T3_OK;
+}
+
+int read_header(const void* d_in, uint64_t n_in, int mode, t3_cfg* seen, uint64_t* n_raw, uint8_t next[3], hipStream_t s) {
+    const uint64_t hw = mode == T3_MODE_FIXED ? 9 : 6;
+    if (n_in < hw) return T3_E_HEADER;                                     // OLD:920
+    uint8_t h[81];
+    HIPCHK(hipMemcpyAsync(h, d_in, hw * 9, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return header_parse(h, n_in, mode, *seen, n_raw, next);
+}
+}  // namespace
+
+namespace t3 {
+int decode_init(const RsTables*) {
+    // Z[0]: one zero byte through the byte-wise register update; Z[j+1] = Z[j] o Z[j]
+    std::vector<uint32_t> z((size_t)kCrcPows * 32);
+    uint32_t tbl[256];
+    for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int j = 0; j < 8; ++j) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1); tbl[i] = c; }
+    for (int i = 0; i < 32; ++i) { const uint32_t x = 1u << i; z[i] = tbl[x & 0xFF] ^ (x >> 8); }
+    for (int j = 1; j < kCrcPows; ++j)
+        for (int i = 0; i < 32; ++i) { uint32_t x = z[(size_t)(j - 1) * 32 + i], y = 0; for (int q = 0; q < 32; ++q) if (x >> q & 1u) y ^= z[(size_t)(j - 1) * 32 + q]; z[(size_t)j * 32 + i] = y; }
+    HIPCHK(hipMalloc((void**)&d_zpow, z.size() * 4));
+    HIPCHK(hipMemcpy(d_zpow, z.data(), z.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&d_crc_acc, 64));
+    return T3_OK;
+}
+}  // namespace t3
+
+extern "C" {
+
+int t3hip_read_header_dev(const void* d_in, uint64_t n_in, int mode, t3_cfg* out_cfg, uint64_t* n_raw, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!out_cfg || (n_in && !d_in)) return T3_E_ARG;
+    uint8_t next[3];
+    return read_header(d_in, n_in, mode, out_cfg, n_raw, next, (hipStream_t)stream);
+}
+
+int t3hip_decode_body_dev(const void* d_in, uint64_t n_in, const t3_cfg* cfg, uint64_t n_raw, void* d_out, uint64_t cap, uint64_t* n_out,
+                          int to_pixels, uint32_t* d_fail, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!cfg || !n_out || !d_fail) return T3_E_ARG;
+    const ScrCycle sc = scrambler_cycle(cfg->seed_a, cfg->seed_b, cfg->seed_s0);
+    return decode_body(d_in, n_in, *cfg, n_raw, sc.next, d_out, cap, n_out, to_pixels, d_fail, (hipStream_t)stream);
+}
+
+int t3hip_decode_profile_dev(const void* d_in, uint64_t n_in, t3_cfg* seen, void* d_out, uint64_t cap, uint64_t* n_out, int to_pixels, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!seen || !n_out || (n_in && !d_in)) return T3_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    *n_out = 0;
+    if (seen->profile == T3_RAW_MODE) {                                       // OLD:998-1002
+        const uint64_t units = to_pixels ? 2 * n_in : n_in; *n_out = units;
+        if (units > cap) return T3_E_CAPACITY;
+        if (!n_in) return T3_OK;
+        if (to_pixels) return t3hip_unpack_words_dev(d_in, n_in, d_out, stream);
+        HIPCHK(hipMemcpyAsync(d_out, d_in, n_in * 9, hipMemcpyDeviceToDevice, s));
+        return T3_OK;
+    }
+    uint64_t n_raw = 0; uint8_t next[3];
+    int rc = read_header(d_in, n_in, seen->mode, seen, &n_raw, next, s);
+    if (rc) return rc;
+    uint32_t* flag = api_flag();
+    HIPCHK(hipMemsetAsync(flag, 0, 4, s));
+    rc = decode_body(d_in, n_in, *seen, n_raw, next, d_out, cap, n_out, to_pixels, flag, s);
+    if (rc) { if (rc != T3_E_CAPACITY) *n_out = 0; return rc; }
+    uint32_t nfail = 0;
+    HIPCHK(hipMemcpyAsync(&nfail, flag, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (nfail) { *n_out = 0; return T3_E_RS; }                                // OLD:987,1017: false, out stays empty
+    return T3_OK;
+}
+
+static int decode_host(const void* in, uint64_t n_in, t3_cfg* seen, void* out, uint64_t cap, uint64_t* n_out, int to_pixels) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!seen || !n_out || (n_in && !in)) return T3_E_ARG;
+    void *di, *dout; int rc = api_scratch(0, n_in * 9 + 64, &di); if (rc) return rc;
+    const uint64_t unit = to_pixels ? 6 : 9, dcap = (to_pixels ? 2 : 1) * (n_in + 16);
+    rc = api_scratch(1, dcap * unit + 64, &dout); if (rc) return rc;
+    hipStream_t s = api_stream();
+    if (n_in) HIPCHK(hipMemcpyAsync(di, in, n_in * 9, hipMemcpyHostToDevice, s));
+    rc = t3hip_decode_profile_dev(di, n_in, seen, dout, dcap, n_out, to_pixels, s);
+    if (rc) return rc;
+    if (*n_out > cap) return T3_E_CAPACITY;
+    if (*n_out) HIPCHK(hipMemcpyAsync(out, dout, *n_out * unit, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return T3_OK;
+}
+int t3hip_decode_profile(const void* in, uint64_t n_in, t3_cfg* seen, void* out, uint64_t cap, uint64_t* n_out) { return decode_host(in, n_in, seen, out, cap, n_out, 0); }
+int t3hip_decode_frame(const void* in, uint64_t n_in, t3_cfg* seen, void* px, uint64_t cap_px, uint64_t* n_px) { return decode_host(in, n_in, seen, px, cap_px, n_px, 1); }
+
+int t3hip_rs_decode_blocks_dev(int k, int mode, uint8_t* d_code, uint64_t n_blocks, uint8_t* d_data, uint8_t* d_ok, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!valid_k(k) || mode < 0 || mode > 1) return T3_E_ARG;
+    if (!n_blocks) return T3_OK;
+    if (!d_code || !d_data || !d_ok) return T3_E_ARG;
+    hipLaunchKernelGGL(rs_decode_blocks_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_code, n_blocks, k, mode, api_tables(), d_data, d_ok);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+
+int t3hip_inject_errors_dev(void* d_words, uint64_t first_sym, uint64_t n_blocks, uint32_t seed, int max_err, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (max_err < 0 || max_err > 26) return T3_E_ARG;
+    if (!n_blocks) return T3_OK;
+    if (!d_words) return T3_E_ARG;
+    hipLaunchKernelGGL(inject_errors_kernel, dim3(grid_for(n_blocks, 256)), dim3(256), 0, (hipStream_t)stream, (uint8_t*)d_words + first_sym, n_blocks, seed, max_err);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+
+uint64_t t3hip_frame_record_scratch_bytes(uint64_t) { return 64; }
+int t3hip_frame_record_dev(const void* d_words, uint64_t n_words, uint64_t frame_idx, const t3_cfg* cfg, t3_frame_record* d_rec,
+                           void* d_scratch, uint64_t scratch_bytes, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!cfg || !d_rec || (n_words && !d_words) || !d_scratch || scratch_bytes < 8) return T3_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    CrcArgs c; memset(&c, 0, sizeof c);
+    c.data = (const uint8_t*)d_words; c.n_bytes = 9 * n_words; c.chunk_bytes = 2304;      // 256 words per lane
+    c.n_chunks = (uint32_t)((c.n_bytes + c.chunk_bytes - 1) / c.chunk_bytes);
+    c.chunk_crc = (uint32_t*)d_scratch; c.sym_sum = (uint32_t*)d_scratch + 1; c.zpow = d_zpow;
+    HIPCHK(hipMemsetAsync(d_scratch, 0, 8, s));
+    if (c.n_chunks) { hipLaunchKernelGGL(crc_chunks_kernel, dim3((c.n_chunks + 255) / 256), dim3(256), 0, s, c); HIPCHK(hipGetLastError()); }
+    hipLaunchKernelGGL(frame_record_kernel, dim3(1), dim3(64), 0, s, c, (const uint8_t*)d_words, n_words, frame_idx, (uint32_t)cfg->profile, (uint32_t)cfg->mode, (void*)d_rec);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+
+int t3hip_index_assemble(t3_frame_record* recs, uint64_t n, uint64_t first_payload_offset) {
+    if (n && !recs) return T3_E_ARG;
+    std::sort(recs, recs + n, [](const t3_frame_record& x, const t3_frame_record& y) { return x.frame_idx < y.frame_idx; });
+    uint64_t off = first_payload_offset;
+    for (uint64_t i = 0; i < n; ++i) { recs[i].byte_offset = off; off += 9 * recs[i].n_words; }
+    return T3_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// t3_device.h — argument blocks shared by the host launcher (t3_api.cpp) and the gfx950 kernels
+// (t3_kernels.hip).  Plain structs passed by value as kernel arguments.
+#pragma once
+#include <stdint.h>
+
+namespace t3 {
+
+enum FrontEnd : int { FE_PIXELS = 0, FE_WORDS = 1 };
+
+constexpr int kMaxWaves = 16;            // 1024-thread workgroup
+constexpr int kGroupSyms = 52;           // symbols one phase-1 lane produces from pixels: 12 px = 72 B -> 52 symbols
+constexpr int kGroupPx = 12;
+constexpr int kGroupSymsW = 104;         // from raw words: 12 words = 108 B -> 104 symbols
+constexpr int kGroupWords = 12;
+
+struct DevDiv { uint32_t mul, sh, d; };
+
+// K2: fused [pack ->] regroup -> [2-D interleave] -> 9-band split -> RS parity -> scramble -> band-serial emit
+struct EncArgs {
+    const uint8_t* in;              // pixels (6 B each) or raw Word27 (9 B each), 16-B aligned
+    uint8_t*  body_out;             // address of body symbol 0 (final stream + header, or scratch when a beacon pass follows)
+    uint8_t*  frame_out;            // final stream base; header/pad written by tile 0 when non-null
+    const uint32_t* lut_img;        // concatenated LUT images of the k's in use (global)
+    uint32_t  lut_bytes;            // total bytes to stage into LDS (multiple of 16)
+    uint64_t  n_units;              // real pixels / words in `in`
+    uint64_t  n_units_pad;          // pixels: 2*n_words (odd count pads one zero pixel, OLD:730); words: = n_units
+    uint32_t  n_sym;                // stream symbols (ceil(26 W / 3))
+    uint32_t  n_tiles;
+    uint32_t  Lq;                   // data symbols per band per tile; tile = 9*Lq stream symbols
+    uint32_t  band_k[9];
+    uint32_t  band_nb_tile[9];      // blocks per tile
+    uint32_t  band_blocks[9];       // blocks in the frame
+    uint32_t  band_lut_off[9];      // LDS byte offset of the band's LUT
+    uint32_t  band_out_off[9];      // LDS byte offset of the band's staging run (16-B aligned, 16 B slack)
+    uint32_t  band_boff6[9];        // (band_body_off + 4) % 6 : scrambler cycle phase of the band's first symbol
+    uint64_t  band_body_off[9];
+    uint32_t  wave_band[kMaxWaves]; // phase-2 role of each wave: band ...
+    uint32_t  wave_pair0[kMaxWaves];// ... and first block-pair it covers
+    uint32_t  n_waves;
+    uint32_t  sym_off, stage_off, lds_bytes;   // LDS carve-up (stage and out staging share one region)
+    uint32_t  stage_groups;         // capacity of the input staging region, in lane groups
+    uint32_t  cyc24; uint32_t pre0, pre1;      // scrambler: 6-periodic tail as 2-bit fields (x2), two pre-period states
+    uint32_t  il_on, il_w, il_A;    // 2-D boustrophedon: row width, chunk area (clamped to n_sym)
+    DevDiv    div_A, div_w;
+    uint32_t  hdr_syms; uint32_t pad_bytes;    // header symbols; zero bytes after the last symbol (OLD:1164-1167)
+    uint64_t  out_syms;
+    uint8_t   hdr[84];
+};
+
+// beacon insertion pass (OLD:1118-1141): framed[q] = beacon | body[q - #beacons before q] | 0
+struct BeaconArgs {
+    const uint8_t* body; uint8_t* frame_out;
+    uint64_t body_syms, framed_syms;
+    uint32_t period, slot, sym, hdr_syms, pad_bytes;
+    uint8_t  hdr[84];
+};
+
+}  // namespace t3

@@ -1,0 +1,89 @@
+// t3_host.hpp — host-side constants and closed-form stream geometry for the Word27 path.
+// Pure C++17 (no HIP): field tables, generator / parity matrices, kernel LUT images, scrambler cycle,
+// 27-symbol header + ternary CRC-12, frame layout and encode-tile planning.
+// OLD:n = reference old/include/ternary_image_codec_v6_min.hpp line n (cited for parity checks).
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+#include "../../include/t3hip.h"
+#include "t3_rs_core.h"
+
+namespace t3 {
+
+// ---- GF(27) ------------------------------------------------------------------------------------
+struct Field {
+    RsTables t;            // mul/add/neg/inv/exp
+    int16_t  log[27];
+    uint8_t  exp78[78];    // the reference's tripled exp table (OLD:457)
+    uint8_t  prim;
+};
+const Field& field();
+inline RsView rs_view(const RsTables& t) { return RsView{t.mul, t.add, t.neg, t.inv, t.exp}; }
+
+// ---- RS(26,k) constants ---------------------------------------------------------------------------
+bool valid_k(int k);
+int  k_of_band_profile(uint8_t bp);                 // OLD:1089-1100: {24,22,20,18}[bp%4]
+void rs_generator(int k, uint8_t* g /*r+1*/);      // OLD:501-516
+// P[i*r+j]: parity_j = sum_i d_i P[i][j].  COMPAT = the reference's recurrence applied to unit vectors
+// (OLD:517-535, a GF(27)-linear map); FIXED = systematic RS with roots alpha^1..alpha^r.
+void rs_parity_matrix(int k, int mode, uint8_t* P);
+bool rs_decode_host(int k, uint8_t* c26, bool fixed);   // decode_block OLD:546-662 on the host (header)
+
+// ---- encode LUT image consumed by the HIP kernels -------------------------------
+// For data position p and symbol value d, the contribution of d at p to every parity trit, as 6-bit
+// SWAR fields (5 per dword), plus the two non-trivial scrambled images of d.
+// dword layout ("main" = first min(r,5) parities, plane-major; "extra" = the remaining ones, 3 fields each):
+//   dw0/dw1/dw2 : trit 0/1/2 of parity j at bits [6j, 6j+6), j < min(r,5)
+//   dw3..       : extra parity e = j-5: trit c at field 3e+c (5 fields per dword)
+//   scr         : T1[d] | T2[d] << 5, T_s[d] = d + 13 s trit-wise  (scramble_symbol OLD:81-87)
+struct LutGeom {
+    int k, r;
+    int n_dw;          // accumulator dwords: r=2,4 -> 3; r=6 -> 4; r=8 -> 5
+    int scr_dw;        // dword that carries the scramble images in its top bits
+    int scr_shift;     // bit position of T1 inside that dword (T2 at +5)
+    int slab_bytes;    // LDS bytes per data position (27 entries per table, tables 256-B aligned for b64)
+    int total_bytes;   // k * slab_bytes
+};
+LutGeom lut_geom(int k);
+// Image: for position p: [tableA: 27 x {dw0,dw1}] pad to 256 B, [tableB: 27 x {dw2,dw3}] pad to 256 B
+// (r>=6) or [tableB32: 27 x dw2] pad to 128 B (r<6), [tableC32: 27 x dw4] pad to 128 B (r=8).
+void build_encode_lut(int k, int mode, std::vector<uint32_t>& image);
+
+// ---- scrambler (OLD:77-94) ------------------------------------------------------------------------
+struct ScrCycle {
+    uint8_t pre[2];      // state applied to body symbols 0 and 1
+    uint8_t cyc[6];      // state applied to body symbol i >= 2: cyc[(i-2)%6]
+    uint32_t cyc24;      // cyc as 2-bit fields, repeated twice (rotation by shift)
+    uint8_t next[3];     // next-state table in uint32 wrap-around arithmetic
+};
+ScrCycle scrambler_cycle(uint32_t a, uint32_t b, uint32_t s0);
+ScrCycle scrambler_cycle_from_next(const uint8_t next[3], uint32_t s0);
+
+// ---- header (OLD:155-380) ---------------------------------------------------------------------------
+void crc12(const uint8_t* trits, int n, uint8_t out[12]);
+void header_pack(const t3_cfg& c, uint32_t frame_seq, uint32_t band_map_hash, uint8_t s[27]);
+bool header_check(const uint8_t s[27]);
+void header_unpack(const uint8_t s[27], t3_cfg& out, uint32_t* frame_seq, uint32_t* band_map_hash);
+// coded header in front of the body: COMPAT 52 symbols (OLD:1142-1162), FIXED 81
+int  header_encode(const t3_cfg& c, uint64_t n_raw_words, uint8_t* out /*>=81*/);
+// parse the first 6 (COMPAT) / 9 (FIXED) words of a coded stream. Returns T3_OK or T3_E_HEADER; on success
+// `seen` is overwritten as OLD:1006-1013 does and (FIXED) *n_raw and next[] are filled.
+int  header_parse(const uint8_t* words, uint64_t n_words, int mode, t3_cfg& seen, uint64_t* n_raw, uint8_t next[3]);
+uint8_t beacon_symbol(uint8_t profile, uint16_t frame_seq_mod, uint8_t health);   // OLD:107-113
+
+// ---- frame geometry ----------------------------------------------------------------------------------
+int  plan(uint64_t n_raw_words, const t3_cfg& c, t3_layout& L);    // T3_OK / T3_E_ARG
+bool want_interleave(const t3_cfg& c);                              // OLD:1083
+// COMPAT decoder framing (OLD:948-993): per slot, symbols and whole 26-blocks seen by the reference decoder
+struct DecLayoutCompat {
+    uint64_t body_words; uint64_t band_syms[9]; uint64_t band_blocks[9]; uint64_t use_off[9]; uint64_t use_syms;
+    uint8_t band_k[9]; uint64_t out_words;
+};
+void plan_decode_compat(uint64_t n_in_words, const t3_cfg& seen, DecLayoutCompat& D);
+
+// Unsigned division by a runtime constant on the device: q = (n * mul) >> 32 >> sh (n < 2^32).
+struct FastDiv { uint32_t mul, sh, d; };
+FastDiv fastdiv(uint32_t d);
+
+}  // namespace t3

@@ -1,0 +1,17 @@
+// t3_kernels.h — kernel declarations for the launcher (hipcc only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "t3_device.h"
+#include "t3_rs_core.h"
+
+namespace t3 {
+
+__global__ void pack_pixels_kernel(const uint16_t* px, uint64_t n_px, uint8_t* words, uint64_t n_words);
+__global__ void unpack_words_kernel(const uint8_t* words, uint64_t n_words, uint16_t* px);
+template <int FE> __global__ void encode_kernel(const EncArgs a);
+__global__ void beacon_kernel(const BeaconArgs a);
+__global__ void rs_encode_blocks_kernel(const uint8_t* data, uint64_t n_blocks, int k, const uint8_t* P, const RsTables* tab, uint8_t* code);
+
+}  // namespace t3

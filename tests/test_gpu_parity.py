@@ -1,0 +1,290 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the oracle on the same seeded inputs and
+against the golden vectors captured from the reference.  Bit-exact everywhere (integer/byte work)."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_vectors.json")))
+
+CFGS = {
+    "p3_uniform20": dict(profile=2, uep=2),
+    "p2_luma": dict(profile=1, uep="luma"),
+    "p5_tile64_luma": dict(profile=4, uep="luma", tile=(64, 64)),
+    "p5_tile64_uniform20": dict(profile=4, uep=2, tile=(64, 64)),
+    "p5_tile7x5_mixed4": dict(profile=4, uep=[0, 1, 2, 3, 0, 1, 2, 3, 1], tile=(7, 5)),
+    "p2_beacon83": dict(profile=1, uep=1, beacon=(83, 2, 1)),
+    "p1_beacon3_slot8": dict(profile=0, uep=0, beacon=(3, 8, 1), seed=(2, 1, 0)),
+    "p4_seed_wrap": dict(profile=3, uep=3, seed=(0xFFFFFFFF, 0xFFFFFFFE, 5)),
+    "p2_tile_ignored": dict(profile=1, uep=1, tile=(64, 64)),
+    "p5_beacon_slot9": dict(profile=4, uep=1, tile=(3, 4), beacon=(5, 9, 1)),
+    "p5_wide_tile": dict(profile=4, uep=2, tile=(5000, 3)),
+    "p3_seed_fixedpoint": dict(profile=2, uep=2, seed=(0, 2, 1)),
+    "p3_seed_period2": dict(profile=2, uep=2, seed=(2, 0, 1)),
+}
+
+
+def both(t3, kw, mode=0):
+    return t3.make_cfg(mode=mode, **kw), ol.make_cfg(mode=mode, **kw)
+
+
+def rand_pixels(rng, n, in_range=True):
+    px = np.zeros(n, ol.PIXEL_DT)
+    if in_range:
+        px["Yq"] = rng.integers(0, 243, n); px["Cbq"] = rng.integers(-40, 41, n); px["Crq"] = rng.integers(-40, 41, n)
+    else:
+        px["Yq"] = rng.integers(0, 65536, n); px["Cbq"] = rng.integers(-32768, 32768, n); px["Crq"] = rng.integers(-32768, 32768, n)
+    return px
+
+
+def test_pack_unpack(gpu, orc):
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 7, 64, 1001, 65536):
+        for in_range in (True, False):
+            px = rand_pixels(rng, n, in_range)
+            w = gpu.encode_raw_pixels_to_words(px)
+            assert np.array_equal(w, orc.pack_pixels(px)), (n, in_range)
+            assert np.array_equal(gpu.decode_raw_words_to_pixels(w), orc.unpack_words(w))
+    w = rng.integers(0, 256, size=(4096, 9), dtype=np.uint8)       # non-canonical symbols
+    assert np.array_equal(gpu.decode_raw_words_to_pixels(w), orc.unpack_words(w))
+    assert len(gpu.encode_raw_pixels_to_words(np.zeros(0, ol.PIXEL_DT))) == 0
+    g = GOLD["pack"]
+    q = np.array([tuple(p) for p in g["quirk_px"]], ol.PIXEL_DT)
+    assert list(gpu.encode_raw_pixels_to_words(q).reshape(-1)) == g["quirk_words"]
+    assert gpu.encode_raw_pixels_to_words_subword(q, 13) is None and gpu.encode_raw_pixels_to_words_subword(q, 24) is not None
+
+
+@pytest.mark.parametrize("k", [24, 22, 20, 18])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_rs_block_level(gpu, orc, k, mode):
+    import torch
+    rng = np.random.default_rng(10 * k + mode)
+    gk = GOLD["rs"][str(k)]
+    data = np.concatenate([np.array(gk["enc_data"], np.uint8).reshape(-1, k), rng.integers(0, 27, size=(5000, k), dtype=np.uint8)])
+    d = torch.from_numpy(data).cuda(); code = torch.zeros((len(data), 26), dtype=torch.uint8, device="cuda")
+    gpu.rs_encode_blocks_dev(k, mode, d.data_ptr(), len(data), code.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(code.cpu().numpy(), orc.rs_encode_blocks(k, data, mode))
+    if mode == 0:
+        assert list(code.cpu().numpy()[:24].reshape(-1)) == gk["enc_code"]
+    # decode: golden triples (reference behaviour), then random corruptions of valid and invalid codewords
+    t = (26 - k) // 2
+    rx = [np.array(gk["dec_in"], np.uint8).reshape(-1, 26)] if mode == 0 else []
+    base = orc.rs_encode_blocks(k, data[:3000], mode=1)
+    for e in range(0, t + 3):
+        c = base[500 * (e % 6):500 * (e % 6) + 500].copy()
+        for row in c:
+            pos = rng.choice(26, size=e, replace=False)
+            row[pos] = (row[pos] + rng.integers(1, 27, size=e)) % 27
+        rx.append(c)
+    rx.append(rng.integers(0, 27, size=(2000, 26), dtype=np.uint8))
+    rx = np.concatenate(rx)
+    c = torch.from_numpy(rx).cuda(); dk = torch.zeros((len(rx), k), dtype=torch.uint8, device="cuda"); ok = torch.zeros(len(rx), dtype=torch.uint8, device="cuda")
+    gpu.rs_decode_blocks_dev(k, mode, c.data_ptr(), len(rx), dk.data_ptr(), ok.data_ptr())
+    torch.cuda.synchronize()
+    oc, odk, ook = orc.rs_decode_blocks(k, rx, mode)
+    assert np.array_equal(ok.cpu().numpy(), ook)
+    assert np.array_equal(c.cpu().numpy(), oc)
+    assert np.array_equal(dk.cpu().numpy()[ook == 1], odk[ook == 1])
+    if mode == 0:
+        n = len(gk["dec_ok"])
+        assert list(ok.cpu().numpy()[:n]) == gk["dec_ok"] and list(c.cpu().numpy()[:n].reshape(-1)) == gk["dec_inout"]
+
+
+@pytest.mark.parametrize("name", sorted(CFGS))
+def test_encode_profile_vs_oracle(gpu, orc, name):
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    cfg, ocfg = both(gpu, CFGS[name])
+    for n in (0, 1, 2, 3, 9, 64, 270, 271, 1000, 4099, 70001):
+        for canonical in (True, False):
+            raw = rng.integers(0, 27 if canonical else 256, size=(n, 9), dtype=np.uint8)
+            ok, enc = gpu.encode_profile_from_raw(raw, cfg)
+            rc, want = orc.encode_profile(raw, ocfg)
+            assert ok and rc == 0 and enc.shape == want.shape, (name, n)
+            assert np.array_equal(enc, want), (name, n, canonical, np.flatnonzero(enc.reshape(-1) != want.reshape(-1))[:10])
+
+
+@pytest.mark.parametrize("name", sorted(CFGS))
+def test_encode_frame_vs_oracle(gpu, orc, name):
+    rng = np.random.default_rng(zlib.crc32(name.encode()) + 5)
+    cfg, ocfg = both(gpu, CFGS[name])
+    for n in (0, 1, 2, 5, 64, 539, 540, 541, 2161, 65536, 200003):
+        px = rand_pixels(rng, n, in_range=(n % 2 == 0))
+        ok, enc = gpu.encode_frame(px, cfg)
+        rc, want = orc.encode_frame(px, ocfg, cap=n + 64)
+        assert ok and rc == 0 and enc.shape == want.shape, (name, n)
+        assert np.array_equal(enc, want), (name, n, np.flatnonzero(enc.reshape(-1) != want.reshape(-1))[:10])
+
+
+def test_raw_mode_roundtrip_config1(gpu, orc):
+    """BASELINE config 1: 256x256 synthetic frame, RAW mode, bit-exact Word27 round trip."""
+    px = orc.lcg_pixels(256 * 256)
+    ectx = gpu.EncoderContext(); ectx.cfg.profile = gpu.ProfileID.RAW_MODE
+    raw = gpu.encode_raw_pixels_to_words(px)
+    ok, enc = gpu.encode_profile_from_raw(raw, ectx)
+    assert ok and ol.fnv_hex(enc) == GOLD["frames"]["256x256"]["raw_hash"] == "9d2b4253c595d3ff"
+    dctx = gpu.DecoderContext(); dctx.cfg_last_seen.profile = gpu.ProfileID.RAW_MODE
+    ok, back = gpu.decode_profile_to_raw(enc, dctx)
+    assert ok and np.array_equal(back, raw)
+    assert np.array_equal(gpu.decode_raw_words_to_pixels(back), px)
+    ok, enc2 = gpu.encode_frame(px, ectx)
+    assert ok and np.array_equal(enc2, raw)
+
+
+@pytest.mark.parametrize("res", ["8x8", "256x256", "1920x1080"])
+def test_golden_frame_hashes(gpu, orc, res):
+    """Frame hashes captured from the unmodified reference (tests/golden/make_golden.py)."""
+    w, h = (int(x) for x in res.split("x"))
+    px = orc.lcg_pixels(w * h)
+    for name, ent in GOLD["frames"][res]["cfgs"].items():
+        cfg = ol.cfg_from_dict(ent["cfg"])
+        tcfg = gpu.make_cfg(profile=cfg.profile, uep=list(cfg.band_profile), tile=(cfg.tile_w, cfg.tile_h), seed=(cfg.seed_a, cfg.seed_b, cfg.seed_s0),
+                            beacon=(cfg.beacon_words_period, cfg.beacon_band_slot, cfg.beacon_enabled))
+        ok, enc = gpu.encode_frame(px, tcfg)
+        assert ok and len(enc) == ent["out_words"], (res, name)
+        assert ol.fnv_hex(enc) == ent["hash"], (res, name)
+        assert list(enc[:8].reshape(-1)) == ent["first_words"] and list(enc[-2:].reshape(-1)) == ent["last_words"]
+    st = GOLD["selftest64"]
+    i = np.arange(64); sp = np.zeros(64, ol.PIXEL_DT); sp["Yq"] = (i * 7) % 243; sp["Cbq"] = (i * 3) % 81 - 40; sp["Crq"] = (i * 5) % 81 - 40
+    raw = gpu.encode_raw_pixels_to_words(sp)
+    assert list(raw.reshape(-1)) == st["raw_words"]
+    ok, enc = gpu.encode_profile_from_raw(raw, gpu.make_cfg(profile=1, uep="luma"))
+    assert list(enc.reshape(-1)) == st["p2_luma_words"]
+
+
+@pytest.mark.parametrize("name", ["p3_uniform20", "p5_tile64_luma"])
+def test_8k_frame_hash(gpu, orc, name):
+    """BASELINE configs 2 and 3 at full size: device-resident fused encode, hash captured from the reference."""
+    import torch
+    ent = GOLD["frames"]["7680x4320"]["cfgs"][name]
+    px = orc.lcg_pixels(7680 * 4320)
+    c = ol.cfg_from_dict(ent["cfg"])
+    cfg = gpu.make_cfg(profile=c.profile, uep=list(c.band_profile), tile=(c.tile_w, c.tile_h))
+    d_px = torch.from_numpy(px.view(np.uint8)).cuda()
+    cap = gpu.encoded_words(len(px) // 2, cfg)
+    assert cap == ent["out_words"]
+    d_out = torch.zeros(cap * 9, dtype=torch.uint8, device="cuda")
+    n = gpu.encode_frame_dev(d_px.data_ptr(), len(px), cfg, d_out.data_ptr(), cap, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    enc = d_out.cpu().numpy()
+    assert n == ent["out_words"] and ol.fnv_hex(enc) == ent["hash"]
+    assert orc.crc32(enc) == ent["crc32"]
+
+
+def test_decode_compat_golden_streams(gpu, orc):
+    for g in GOLD["decode_streams"]:
+        s = np.array(g["in_words"], np.uint8).reshape(-1, 9)
+        dctx = gpu.DecoderContext()
+        ok, out = gpu.decode_profile_to_raw(s, dctx)
+        assert ok == g["ok"], g["name"]
+        assert list(out.reshape(-1)) == g["out_words"], g["name"]
+        seen = dctx.cfg_last_seen.as_dict()
+        for key, v in g["seen"].items():
+            if key not in ("mode", "superframe_words"):
+                assert seen[key] == v, (g["name"], key)
+    for g in GOLD["decode_of_encode"]:          # the reference decoder on the reference encoder's output
+        c = ol.cfg_from_dict(g["cfg"])
+        cfg = gpu.make_cfg(profile=c.profile, uep=list(c.band_profile), tile=(c.tile_w, c.tile_h), beacon=(c.beacon_words_period, c.beacon_band_slot, c.beacon_enabled))
+        ok, enc = gpu.encode_frame(orc.lcg_pixels(g["n_px"], g["lcg_seed"]), cfg)
+        dctx = gpu.DecoderContext()
+        ok, out = gpu.decode_profile_to_raw(enc, dctx)
+        assert ok == g["ok"] and len(out) == g["n_out"], g["name"]
+        seen = dctx.cfg_last_seen.as_dict()
+        for key, v in g["seen"].items():
+            if key not in ("mode", "superframe_words"):
+                assert seen[key] == v, (g["name"], key)
+
+
+@pytest.mark.parametrize("name", ["p3_uniform20", "p2_luma", "p5_tile64_luma", "p2_beacon83", "p1_beacon3_slot8", "p5_tile7x5_mixed4"])
+def test_decode_compat_vs_oracle(gpu, orc, name):
+    from test_oracle_vs_ref import decoder_consistent_stream
+    rng = np.random.default_rng(zlib.crc32(name.encode()) + 9)
+    kw = dict(CFGS[name])
+    if isinstance(kw.get("uep"), list):
+        kw["uep"] = [x % 3 for x in kw["uep"]]
+    ocfg = ol.make_cfg(**kw)
+    for nbw in (0, 1, 25, 26, 27, 130, 600, 5000):
+        for corrupt in (0, 1, 5):
+            s = decoder_consistent_stream(orc, rng, ocfg, nbw, corrupt)
+            dctx = gpu.DecoderContext(); oseen = ol.make_cfg()
+            ok, out = gpu.decode_profile_to_raw(s, dctx)
+            rc, want = orc.decode_profile(s, oseen)
+            assert ok == (rc == 0), (name, nbw, corrupt)
+            assert np.array_equal(out, want if rc == 0 else want[:0])
+            a, b = dctx.cfg_last_seen.as_dict(), oseen.as_dict()
+            assert {k: v for k, v in a.items() if k != "mode"} == {k: v for k, v in b.items() if k != "mode"}
+            if rc == 0:
+                okp, px = gpu.decode_frame(s, gpu.DecoderContext())
+                assert okp and np.array_equal(px, orc.unpack_words(want))
+    for n in (0, 3, 5, 6):
+        s = rng.integers(0, 27, size=(n, 9), dtype=np.uint8)
+        ok, out = gpu.decode_profile_to_raw(s, gpu.DecoderContext())
+        assert ok == (orc.decode_profile(s, ol.make_cfg())[0] == 0)
+
+
+@pytest.mark.parametrize("name", sorted(k for k in CFGS if k != "p5_beacon_slot9"))
+def test_fixed_mode_roundtrip_with_errors(gpu, orc, name):
+    """BASELINE config 5 semantics at test size: FIXED (v6c) encode -> inject <= t symbol errors per block -> decode ->
+    exact recovery; and the HIP FIXED path equals the oracle's restatement of the same spec."""
+    rng = np.random.default_rng(zlib.crc32(name.encode()) + 13)
+    cfg, ocfg = both(gpu, CFGS[name], mode=1)
+    for n in (1, 2, 64, 541, 4321, 100003):
+        px = rand_pixels(rng, n)
+        ok, enc = gpu.encode_frame(px, cfg)
+        rc, want = orc.encode_frame(px, ocfg, cap=n + 64)
+        assert ok and rc == 0 and np.array_equal(enc, want), (name, n)
+        L = gpu.plan((n + 1) // 2, cfg)
+        kmin = min(L.band_k)
+        bad = enc
+        if not L.beacon_on:     # body is contiguous 26-symbol blocks: every block gets 0..t errors
+            bad = orc.inject_errors(enc, L.header_syms, L.body_syms // 26, 1234 + n, (26 - max(L.band_k)) // 2)
+            assert (bad != enc).any() or n < 3
+        dctx = gpu.DecoderContext(mode=1)
+        ok, back = gpu.decode_frame(bad, dctx)
+        assert ok, (name, n)
+        padded = np.zeros(2 * ((n + 1) // 2), ol.PIXEL_DT); padded[:n] = px
+        assert np.array_equal(back, padded), (name, n)
+        oseen = ol.make_cfg(mode=1)
+        rc, oback = orc.decode_frame(bad, oseen)
+        assert rc == 0 and np.array_equal(oback, back)
+        seen = dctx.cfg_last_seen.as_dict(); want_seen = oseen.as_dict()
+        assert {k: v for k, v in seen.items()} == {k: v for k, v in want_seen.items()}
+        # too many errors in one block -> detected, reference-style `false`
+        if not L.beacon_on and L.body_syms >= 26 and kmin >= 20:
+            worse = bad.copy().reshape(-1)
+            worse[L.header_syms: L.header_syms + 13] = (worse[L.header_syms: L.header_syms + 13] + 1) % 27
+            okw, _ = gpu.decode_frame(worse.reshape(-1, 9), gpu.DecoderContext(mode=1))
+            rcw, _ = orc.decode_frame(worse.reshape(-1, 9), ol.make_cfg(mode=1))
+            assert okw == (rcw == 0)
+
+
+def test_error_injector_matches_host(gpu, orc):
+    import torch
+    rng = np.random.default_rng(3)
+    w = rng.integers(0, 27, size=(26 * 400 // 9 + 10, 9), dtype=np.uint8)
+    d = torch.from_numpy(w).cuda()
+    gpu.inject_errors_dev(d.data_ptr(), 52, 390, 99, 3)
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy(), orc.inject_errors(w, 52, 390, 99, 3))
+
+
+def test_frame_record(gpu, orc):
+    import torch
+    rng = np.random.default_rng(4)
+    for n in (0, 1, 6, 255, 256, 257, 100000):
+        w = rng.integers(0, 27, size=(n, 9), dtype=np.uint8)
+        d = torch.from_numpy(w).cuda() if n else torch.zeros(16, dtype=torch.uint8, device="cuda")
+        rec = torch.zeros(gpu.FRAME_RECORD_BYTES, dtype=torch.uint8, device="cuda"); scr = torch.zeros(64, dtype=torch.uint8, device="cuda")
+        gpu.frame_record_dev(d.data_ptr(), n, 7, gpu.make_cfg(profile=2, uep=2), rec.data_ptr(), scr.data_ptr())
+        torch.cuda.synchronize()
+        r = gpu.index_assemble(rec.cpu().numpy(), 100)[0]
+        assert (r.frame_idx, r.n_words, r.byte_offset, r.profile) == (7, n, 100, 2)
+        assert r.crc32 == orc.crc32(w) and r.sym_sum == orc.sym_sum(w)
+        assert list(r.header_syms)[: min(54, 9 * n)] == list(w.reshape(-1)[:54])

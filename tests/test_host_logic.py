@@ -1,0 +1,133 @@
+"""CPU-side checks (no GPU): the product's host-only metadata (field tables, generators, parity matrices, header codec,
+stream layout) against the oracle and the golden vectors captured from the reference; the C-ABI library loads and exports
+every symbol include/t3hip.h declares; compute entry points refuse to run without a device (no CPU fallback)."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_vectors.json")))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    return ge.load_package()
+
+
+def to_t3(t3, c):
+    return t3.make_cfg(profile=c.profile, uep=list(c.band_profile), tile=(c.tile_w, c.tile_h), seed=(c.seed_a, c.seed_b, c.seed_s0),
+                       beacon=(c.beacon_words_period, c.beacon_band_slot, c.beacon_enabled), superframe_words=c.superframe_words,
+                       subword=c.subword, centered=c.centered, coset=c.coset, mode=c.mode)
+
+
+def test_abi_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "t3hip.h")).read()
+    names = sorted(set(re.findall(r"\b(t3hip_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 35
+    lib = built.lib()
+    for n in names:
+        assert hasattr(lib, n), "libt3hip.so does not export " + n
+    assert C.sizeof(built.Cfg) == 44 and C.sizeof(built.FrameRecord) == 96
+    assert C.sizeof(ol.Cfg) == C.sizeof(built.Cfg)
+
+
+def test_no_cpu_fallback(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    px = np.zeros(4, built.PIXEL_DT)
+    with pytest.raises(built.T3Error) as e:
+        built.encode_raw_pixels_to_words(px)
+    assert e.value.code == built.E_NODEVICE
+    with pytest.raises(built.T3Error):
+        built.encode_frame(px, built.default_cfg())
+    with pytest.raises(built.T3Error):
+        built.init(0)
+
+
+def test_field_and_rs_constants(built, orc):
+    t, g = built.gf27_tables(), GOLD["gf"]
+    assert list(t["exp"]) == g["exp"] and list(t["log"]) == g["log"] and list(t["mul"]) == g["mul"] and list(t["inv"]) == g["inv"]
+    for k in (24, 22, 20, 18):
+        gk = GOLD["rs"][str(k)]
+        assert list(built.rs_generator(k)) == gk["g"]
+        assert list(built.rs_parity_matrix(k, 0).reshape(-1)) == gk["P_compat"]
+        assert np.array_equal(built.rs_parity_matrix(k, 1), orc.rs_parity_matrix(k, 1))
+        # FIXED codewords have zero syndromes under the decoder's convention: the reference decoder accepts them unchanged
+        d = np.arange(k, dtype=np.uint8) % 27
+        par = np.zeros(26 - k, np.uint8)
+        mul, exp = t["mul"], t["exp"]
+        P = built.rs_parity_matrix(k, 1)
+        for j in range(26 - k):
+            acc = 0
+            for i in range(k):
+                acc = int(orc.lib.t3o_gf_add(C.c_uint8(acc), C.c_uint8(int(mul[int(d[i]) * 27 + int(P[i, j])]))))
+            par[j] = acc
+        cw = np.concatenate([d, par])
+        _, _, ok = orc.rs_decode_blocks(k, cw, mode=0)
+        assert ok[0] == 1
+
+
+def test_header_codec(built, orc):
+    for h in GOLD["header"]:
+        c = built.make_cfg(**{k: v for k, v in dict(profile=h["cfg"]["profile"], uep=h["cfg"]["band_profile"], tile=(h["cfg"]["tile_w"], h["cfg"]["tile_h"]),
+                                                    seed=(h["cfg"]["seed_a"], h["cfg"]["seed_b"], h["cfg"]["seed_s0"]),
+                                                    beacon=(h["cfg"]["beacon_words_period"], h["cfg"]["beacon_band_slot"], h["cfg"]["beacon_enabled"]),
+                                                    subword=h["cfg"]["subword"], centered=h["cfg"]["centered"], coset=h["cfg"]["coset"]).items()})
+        s = built.header_pack(c, h["frame_seq"], h["band_map_hash"])
+        assert list(s) == h["syms"]
+        assert built.header_check(s) == h["check"]
+        u, fs, bh = built.header_unpack(s)
+        want = h["unpacked"]
+        got = u.as_dict()
+        for key in ("profile", "band_profile", "tile_w", "tile_h", "seed_a", "seed_b", "seed_s0", "beacon_words_period", "beacon_band_slot", "beacon_enabled", "subword", "centered", "coset"):
+            assert got[key] == want[key], key
+        assert (fs, bh) == (h["u_frame_seq"], h["u_band_map_hash"])
+    rng = np.random.default_rng(1)
+    for _ in range(100):
+        oc = ol.make_cfg(profile=int(rng.integers(0, 5)), uep=[int(x) for x in rng.integers(0, 4, 9)], tile=(int(rng.integers(0, 65536)), int(rng.integers(0, 65536))),
+                         seed=tuple(int(x) for x in rng.integers(0, 2**32, 3)), beacon=(int(rng.integers(0, 200)), int(rng.integers(0, 12)), int(rng.integers(0, 2))),
+                         subword=int(rng.choice([27, 24, 21, 18, 15])), centered=int(rng.integers(0, 2)), coset=int(rng.integers(0, 3)))
+        fs, bh = int(rng.integers(0, 2**32)), int(rng.integers(0, 2**32))
+        s = built.header_pack(to_t3(built, oc), fs, bh)
+        assert np.array_equal(s, orc.header_pack(oc, fs, bh))
+        bad = s.copy(); bad[int(rng.integers(0, 27))] = (int(bad[int(rng.integers(0, 27))]) + 1) % 27
+        assert built.header_check(bad) == orc.header_check(bad)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_layout_and_coded_header(built, orc, mode):
+    rng = np.random.default_rng(2 + mode)
+    for _ in range(300):
+        oc = ol.make_cfg(profile=int(rng.integers(0, 5)), uep=[int(x) for x in rng.integers(0, 4, 9)], tile=(int(rng.integers(0, 100)), int(rng.integers(0, 100))),
+                         seed=tuple(int(x) for x in rng.integers(0, 2**32, 3)), beacon=(int(rng.integers(0, 40)), int(rng.integers(0, 9 if mode else 12)), int(rng.integers(0, 2))), mode=mode)
+        n = int(rng.integers(0, 5000))
+        assert built.encoded_words(n, to_t3(built, oc)) == orc.encoded_words(n, oc)
+        # the coded header the encoder emits = the first header_syms bytes of the oracle's stream
+        raw = rng.integers(0, 27, size=(min(n, 40), 9), dtype=np.uint8)
+        rc, enc = orc.encode_profile(raw, oc)
+        assert rc == 0
+        hs = built.header_encode(to_t3(built, oc), len(raw))
+        assert len(hs) == (81 if mode else 52)
+        assert np.array_equal(hs, enc.reshape(-1)[: len(hs)])
+    L = built.plan(16588800, built.make_cfg(profile=2, uep=2))      # BASELINE C2
+    assert (L.n_sym, L.body_syms, L.out_words) == (143769600, 186900480, 20766726) and list(L.band_blocks) == [798720] * 9
+    L = built.plan(16588800, built.make_cfg(profile=4, uep="luma", tile=(64, 64)))   # C3
+    assert L.out_words == 19508136 and L.interleave2d == 1
+    assert built.encoded_words(123, built.make_cfg(profile=0xFF)) == 123
+
+
+def test_selftest_inputs_known_answers(orc):
+    """The reference's own self-test inputs (OLD:1186, 1210-1223) with outputs captured from it."""
+    for k in (24, 22, 20, 18):
+        pat = ((np.arange(k) * 5 + 7) % 27).astype(np.uint8)
+        assert list(orc.rs_encode_blocks(k, pat)[0, k:]) == GOLD["rs"][str(k)]["pattern_parity"]
+    assert GOLD["selftests"] == [False, False]
