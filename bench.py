@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the Word27 hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One step = one synthetic 8K (7680x4320) frame through the hot path on each rank, inputs already resident in HBM:
+  1. fused encode, COMPAT arithmetic, P3 / RS(26,20) on all 9 bands, 1-D (BASELINE configs[1]; output hash pinned to the
+     reference's b6c43f2f4aa44763),
+  2. decode of the same frame's FIXED-mode (v6c) stream carrying 0..3 injected symbol errors in every RS block
+     (BASELINE configs[4] semantics; exact recovery of the pixels is asserted after the timed region),
+  3. the frame's index record (CRC-32 + header symbols) for the T3V-style super-frame index.
+Frames are independent, so ranks shard them with no data-path collective (weak scaling); the only exchange is one
+all-gather of the K fixed-size index records per rank at the end of the batch (RCCL), inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement; roofline/cpu_baseline objects included)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H = 7680, 4320
+NPX = W * H
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+GOLD_HASH_C2 = "b6c43f2f4aa44763"
+
+
+def cpu_baseline(orc, ol, px, budget_s=30.0):
+    """The reference's own encoder (oracle/_ref, built from /root/reference in place) on one full 8K frame, 1 thread;
+    decode leg: the C port of the FIXED decoder on a 1/8-frame sample (the reference cannot decode its own streams)."""
+    import numpy as np
+    cfg = ol.make_cfg(profile=2, uep=2)
+    kind = "port"
+    if ol.have_ref():
+        ref = ol.Ref(); kind = "reference"
+        t0 = time.perf_counter(); rc, enc = ref.encode_frame(px, cfg, cap=len(px)); t_enc = time.perf_counter() - t0
+        enc_px = len(px)
+    else:
+        sample = px[: NPX // 8]
+        t0 = time.perf_counter(); rc, enc = orc.encode_frame(sample, cfg, cap=len(sample)); t_enc = time.perf_counter() - t0
+        enc_px = len(sample)
+    assert rc == 0
+    enc_mpix = enc_px / t_enc / 1e6
+    sample = px[: NPX // 8]
+    fcfg = ol.make_cfg(profile=2, uep=2, mode=1)
+    rc, fenc = orc.encode_frame(sample, fcfg, cap=len(sample))
+    nblk = (len(fenc) * 9 - 90) // 26
+    bad = orc.inject_errors(fenc, 90, nblk, 777, 3)
+    t0 = time.perf_counter(); rc, back = orc.decode_frame(bad, ol.make_cfg(mode=1)); t_dec = time.perf_counter() - t0
+    assert rc == 0 and np.array_equal(back, sample)
+    dec_mpix = len(sample) / t_dec / 1e6
+    both = 1.0 / (1.0 / enc_mpix + 1.0 / dec_mpix)
+    return {"value": round(both, 4), "unit": "Mpix/s", "cores": 1, "kind": kind,
+            "sample": "encode: %s encoder on %d px of the 8K frame (%.1f s, %.3f Mpix/s); decode: C port of the FIXED decoder on the first 1/8 frame with injected errors (%.1f s, %.3f Mpix/s); value = 1/(1/enc+1/dec)"
+                      % ("unmodified reference" if kind == "reference" else "C port of the reference", enc_px, t_enc, enc_mpix, t_dec, dec_mpix),
+            "encode_mpix_s": round(enc_mpix, 4), "decode_mpix_s": round(dec_mpix, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--encode-only", action="store_true", help="profiling aid: skip decode + index in the loop")
+    ap.add_argument("--no-verify", action="store_true", help="profiling aid for timing-only ablation builds (results are wrong by construction)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    import oracle_lib as ol
+
+    rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    t3 = ge.load_package()
+    t3.init(local)
+    orc = ol.oracle()
+    stream = torch.cuda.current_stream().cuda_stream
+    dev = torch.device("cuda", local)
+
+    # ---- synthetic input, resident in HBM before any timing (SURVEY §8d generator; frame seed = 12345 + rank) ----
+    px = orc.lcg_pixels(NPX, 12345 + rank)
+    d_px = torch.from_numpy(px.view(np.uint8)).to(dev)
+    cfg = t3.make_cfg(profile=t3.ProfileID.P3_RS26_20, uep=2)
+    fcfg = t3.make_cfg(profile=t3.ProfileID.P3_RS26_20, uep=2, mode=t3.MODE_FIXED)
+    n_enc = t3.encoded_words(NPX // 2, cfg); n_fenc = t3.encoded_words(NPX // 2, fcfg)
+    d_enc = torch.zeros(n_enc * 9 + 64, dtype=torch.uint8, device=dev)
+    d_fenc = torch.zeros(n_fenc * 9 + 64, dtype=torch.uint8, device=dev)
+    d_back = torch.zeros(NPX * 6 + 64, dtype=torch.uint8, device=dev)
+    d_recs = torch.zeros((max(args.steps, 1), t3.FRAME_RECORD_BYTES), dtype=torch.uint8, device=dev)
+    d_scr = torch.zeros(64, dtype=torch.uint8, device=dev)
+    L = t3.plan(NPX // 2, fcfg)
+    t3.encode_frame_dev(d_px.data_ptr(), NPX, fcfg, d_fenc.data_ptr(), n_fenc, stream)
+    t3.inject_errors_dev(d_fenc.data_ptr(), L.header_syms, L.body_syms // 26, 777 + rank, 3, stream)
+    torch.cuda.synchronize()
+
+    def step(i, ev=None):
+        if ev is not None:
+            ev[0].record(stream)
+        t3.encode_frame_dev(d_px.data_ptr(), NPX, cfg, d_enc.data_ptr(), n_enc, stream)
+        if ev is not None:
+            ev[1].record(stream)
+        if args.encode_only:
+            return
+        seen = t3.DecoderContext(mode=t3.MODE_FIXED).cfg_last_seen
+        rc, n = t3.decode_profile_dev(d_fenc.data_ptr(), n_fenc, seen, d_back.data_ptr(), NPX, True, stream)
+        assert rc == 0 and n == NPX, (rc, n)
+        if ev is not None:
+            ev[2].record(stream)
+        t3.frame_record_dev(d_enc.data_ptr(), n_enc, rank * args.steps + i, cfg, d_recs[i % len(d_recs)].data_ptr(), d_scr.data_ptr(), 64, stream)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    events = [[t3.Event(), t3.Event(), t3.Event()] for _ in range(args.steps)]
+    gathered = torch.zeros((world * len(d_recs), t3.FRAME_RECORD_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, events[i])
+    if world > 1 and not args.encode_only:
+        dist.all_gather_into_tensor(gathered, d_recs)      # the one exchange step: super-frame index records
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- correctness of what was just timed (outside the timed region) ----
+    enc = d_enc[: n_enc * 9].cpu().numpy()
+    if rank == 0 and not args.no_verify:
+        assert ol.fnv_hex(enc) == GOLD_HASH_C2, "encoded stream does not match the reference hash"
+    if not args.encode_only:
+        back = d_back[: NPX * 6].cpu().numpy().view(ol.PIXEL_DT)
+        assert np.array_equal(back, px), "FIXED decode did not recover the frame"
+        recs = (gathered if world > 1 else d_recs).cpu().numpy()
+        index = t3.index_assemble(recs.reshape(-1), 0)
+        assert index[0].n_words == n_enc and index[0].crc32 == orc.crc32(enc) if rank == 0 else True
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    enc_ms = [events[i][0].elapsed_ms(events[i][1]) for i in range(args.steps)]
+    dec_ms = [events[i][1].elapsed_ms(events[i][2]) for i in range(args.steps)] if not args.encode_only else [float("nan")]
+    enc_avg = sum(enc_ms) / len(enc_ms); dec_avg = sum(dec_ms) / len(dec_ms)
+    alg_bytes = 6 * NPX + 9 * n_enc                       # read 6 B/px, write 9 B/word = 385,966,134 B
+    achieved = alg_bytes / (enc_avg * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_encode_latest.json")
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+    out = {
+        "metric": "Mpix/s encode+decode 8K RS(26,20)", "value": round(world * args.steps * NPX / dt / 1e6, 3), "unit": "Mpix/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "one 7680x4320 frame per rank per step (BASELINE configs[1]): fused encode COMPAT P3 RS(26,20) 1-D, then FIXED-mode decode of the same frame with 0..3 injected symbol errors per block, then index record" + (" [encode only]" if args.encode_only else ""),
+                   "frame_px": NPX, "coded_words": n_enc, "sharding": "frames per rank, no data-path collective; one all-gather of index records per batch"},
+        "encode_ms": round(enc_avg, 4), "decode_ms": round(dec_avg, 4),
+        "encode_mpix_s": round(NPX / enc_avg / 1e3, 1), "decode_mpix_s": round(NPX / dec_avg / 1e3, 1),
+        "roofline": {"kernel": "encode_kernel<FE_PIXELS>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                     "launch_ms": round(enc_avg, 4)},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(orc, ol, px)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,7 +84,7 @@ typedef struct t3_layout {
     uint64_t body_syms_framed;   /* after beacon insertion (OLD:1118-1141)        */
     uint64_t out_syms;           /* header + framed body                          */
     uint64_t out_words;          /* ceil(out_syms/9) (OLD:1164)                   */
-    uint32_t header_syms;        /* 52 in COMPAT (OLD:1159-1162), 81 in FIXED     */
+    uint32_t header_syms;        /* 52 in COMPAT (OLD:1159-1162), 90 in FIXED     */
     uint8_t  band_k[9];          /* RS k of each band (OLD:1089-1100)             */
     uint8_t  interleave2d;       /* 1 if P5 && tile.w && tile.h (OLD:1083)        */
     uint8_t  beacon_on;          /* 1 if beacon.enabled && period>0 (OLD:1118)    */
@@ -128,7 +128,7 @@ int  t3hip_rs_parity_matrix(int k, int mode, uint8_t* P_out);
 int  t3hip_header_pack(const t3_cfg* cfg, uint32_t frame_seq, uint32_t band_map_hash, uint8_t syms27[27]);
 int  t3hip_header_check(const uint8_t syms27[27]);           /* 1 ok, 0 bad */
 int  t3hip_header_unpack(const uint8_t syms27[27], t3_cfg* out, uint32_t* frame_seq, uint32_t* band_map_hash);
-/* The coded header symbols the encoder emits in front of the body (52 / 81). */
+/* The coded header symbols the encoder emits in front of the body (52 / 90). */
 int  t3hip_header_encode(const t3_cfg* cfg, uint64_t n_raw_words, uint8_t* syms_out, uint32_t* n_syms);
 
 /* ---- host-buffer entry points (what the std::vector API binds) ----------------- */
@@ -158,7 +158,7 @@ int t3hip_encode_profile_dev(const void* d_raw9, uint64_t n_raw, const t3_cfg* c
                              void* d_out9, uint64_t cap_words, uint64_t* n_out, void* stream);
 int t3hip_encode_frame_dev(const void* d_px6, uint64_t n_px, const t3_cfg* cfg,
                            void* d_out9, uint64_t cap_words, uint64_t* n_out, void* stream);
-/* Decode with the header parsed on the host: copies the 6 (COMPAT) / 9 (FIXED) header words
+/* Decode with the header parsed on the host: copies the 6 (COMPAT) / 10 (FIXED) header words
  * device->host and synchronises `stream` once, launches the body kernels, then synchronises
  * again to read the block-failure flag.  `to_pixels` selects Word27 or pixel output. */
 int t3hip_decode_profile_dev(const void* d_in9, uint64_t n_in, t3_cfg* seen,

@@ -372,7 +372,7 @@ static void fixed_ext(const t3_cfg* c, uint64_t n_raw, uint8_t* e) {
 }
 static void fixed_canon(const t3_cfg* c, t3_cfg* o) { *o = *c; for (int b = 0; b < 9; ++b) o->band_profile[b] = c->band_profile[b] % 4; }
 
-static int header_syms_of(const t3_cfg* c) { return c->mode == T3_MODE_FIXED ? 81 : 52; }
+static int header_syms_of(const t3_cfg* c) { return c->mode == T3_MODE_FIXED ? 90 : 52; }
 static void make_header(const t3_cfg* c, uint64_t n_raw, uint8_t* out) {
     uint8_t hp[27], A[18], B[18], g[10];
     t3o_rs_generator(18, g);
@@ -381,7 +381,7 @@ static void make_header(const t3_cfg* c, uint64_t n_raw, uint8_t* out) {
         uint8_t ext[27], C[18]; t3o_header_pack(&cc, 0, 0, hp); fixed_ext(&cc, n_raw, ext);
         memcpy(A, hp, 18); memcpy(B, hp + 18, 9); memcpy(B + 9, ext, 9); memcpy(C, ext + 9, 18);
         rs_encode_fixed(18, A, out); rs_encode_fixed(18, B, out + 26); rs_encode_fixed(18, C, out + 52);
-        out[78] = out[79] = out[80] = 0;
+        memset(out + 78, 0, 12); /* pad to 10 whole words: the body then starts word- and 2-byte-aligned */
     } else { /* OLD:1142-1162 */
         t3o_header_pack(c, 0, 0, hp);
         memcpy(A, hp, 18); memcpy(B, hp + 18, 9); memset(B + 9, 0, 9);
@@ -424,7 +424,7 @@ static int encode_syms(bvec* sy, const t3_cfg* c, uint64_t n_raw, void* out9, ui
         }
         bv_free(&body); body = s2;
     }
-    int hs = header_syms_of(c); uint8_t hdr[81]; make_header(c, n_raw, hdr);
+    int hs = header_syms_of(c); uint8_t hdr[96]; make_header(c, n_raw, hdr);
     uint64_t total = (uint64_t)hs + body.n, words = (total + 8) / 9; /* OLD:1164 */
     *n_out = words;
     if (words > cap) { bv_free(&body); return T3_E_CAPACITY; }
@@ -511,7 +511,7 @@ static int decode_compat(const uint8_t* in, uint64_t n_in, t3_cfg* seen, bvec* u
 
 /* FIXED decode: the inverse of encode_syms(mode=FIXED). */
 static int decode_fixed(const uint8_t* in, uint64_t n_in, t3_cfg* seen, bvec* use, uint64_t* n_raw_out) {
-    if (n_in < 9) return T3_E_HEADER;
+    if (n_in < 10) return T3_E_HEADER;
     uint8_t blk[3][26], dat[3][18], hp[27], ext[27];
     for (int q = 0; q < 3; ++q) { for (int i = 0; i < 26; ++i) blk[q][i] = in[26 * q + i] % 27; if (!rs_decode_block(18, blk[q], dat[q], 1)) return T3_E_HEADER; }
     memcpy(hp, dat[0], 18); memcpy(hp + 18, dat[1], 9); memcpy(ext, dat[1] + 9, 9); memcpy(ext + 9, dat[2], 18);
@@ -519,6 +519,8 @@ static int decode_fixed(const uint8_t* in, uint64_t n_in, t3_cfg* seen, bvec* us
     uint32_t fs, bh; uint16_t mg; uint8_t ver; uint32_t keep_sf = seen->superframe_words;
     t3_cfg c = *seen; t3o_header_unpack(hp, &c, &fs, &bh, &mg, &ver);
     c.mode = T3_MODE_FIXED; c.superframe_words = keep_sf;
+    /* the header packs band triples MSD-first but unpacks them LSD-first (OLD:222-224 vs 327-340): v6c undoes that */
+    for (int g3 = 0; g3 < 3; ++g3) { uint8_t t = c.band_profile[3 * g3]; c.band_profile[3 * g3] = c.band_profile[3 * g3 + 2]; c.band_profile[3 * g3 + 2] = t; }
     uint32_t v = 0; uint64_t q = 0; int i;
     for (v = 0, i = 2; i >= 0; --i) v = v * 27 + ext[i];
     c.tile_w = (uint16_t)(c.tile_w + 27 * v);
@@ -535,7 +537,7 @@ static int decode_fixed(const uint8_t* in, uint64_t n_in, t3_cfg* seen, bvec* us
     /* undo beacon framing */
     uint64_t nsym = (26 * n_raw + 2) / 3, body_syms = 0, blocks[9], len[9];
     for (int b = 0; b < 9; ++b) { len[b] = nsym > (uint64_t)b ? (nsym - b + 8) / 9 : 0; uint64_t k = (uint64_t)band_k(&c, b); blocks[b] = (len[b] + k - 1) / k; body_syms += 26 * blocks[b]; }
-    uint8_t* body = (uint8_t*)malloc(body_syms ? body_syms : 1); const uint8_t* fr = in + 81;
+    uint8_t* body = (uint8_t*)malloc(body_syms ? body_syms : 1); const uint8_t* fr = in + 90;
     if (c.beacon_enabled && c.beacon_words_period > 0) {
         uint64_t w = 0, got = 0;
         while (got < body_syms) { for (int slot = 0; slot < 9 && got < body_syms; ++slot) { if (w % c.beacon_words_period == 0 && slot == c.beacon_band_slot) continue; body[got++] = fr[w * 9 + slot]; } ++w; }

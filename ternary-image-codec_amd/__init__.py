@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libt3hip.so")
+LIB_PATH = os.environ.get("T3HIP_LIB", os.path.join(_HERE, "libt3hip.so"))   # T3HIP_LIB: timing-only ablation builds
 
 PIXEL_DT = np.dtype([("Yq", "<u2"), ("Cbq", "<i2"), ("Crq", "<i2")])
 
@@ -85,6 +85,13 @@ def lib():
     if _lib_handle is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+        try:
+            # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7; when torch is going to be
+            # used next to this library (tests, bench.py) it must be the first to load it, and libt3hip.so then binds
+            # to that already-loaded runtime by SONAME.  Without torch the system runtime under /opt/rocm is used.
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         L.t3hip_strerror.restype = C.c_char_p
         L.t3hip_last_hip_error.restype = C.c_char_p

@@ -1,6 +1,7 @@
 // t3_api.cpp — the C-ABI of libt3hip.so (include/t3hip.h): context, tile planning, kernel launches.
 // Host logic only; all arithmetic on the data path happens in t3_kernels.hip / t3_decode.hip.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -77,11 +78,11 @@ uint64_t gcd64(uint64_t a, uint64_t b) { while (b) { uint64_t t = a % b; a = b; 
 // ------------------------------------------------------------------------------------------------
 // K2 launch planning: one launch covers a set of bands whose k's have a manageable lcm
 // ------------------------------------------------------------------------------------------------
-struct EncLaunch { EncArgs a; uint32_t grid, block; };
+struct EncLaunch { EncArgs a; uint32_t block; int rsel; };   // rsel = 26-k when all bands of the launch share k, else 0
 
 bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, int fe, const LutImage& lut, EncLaunch& out) {
     EncArgs& a = out.a; memset(&a, 0, sizeof a);
-    const uint32_t GS = fe == FE_PIXELS ? kGroupSyms : kGroupSymsW, GB = fe == FE_PIXELS ? 72u : 108u;
+    const uint32_t GS = fe == FE_PIXELS ? kGroupSyms : kGroupSymsW, GB = fe == FE_PIXELS ? kGroupBytes : kGroupBytesW;
     uint64_t Lk = 2;
     for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) Lk = Lk / gcd64(Lk, L.band_k[b]) * L.band_k[b];
     uint32_t lut_bytes = lut.bytes;
@@ -91,16 +92,16 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
         const uint32_t budget = pass == 0 ? 80u * 1024u : 160u * 1024u;
         for (uint32_t q = 2; q <= 4096; q += 2) {
             const uint64_t Lq = Lk * q; if (9 * Lq > 60000) break;
-            uint32_t waves = 0, pairs_total = 0, outb = 0;
+            uint32_t waves = 0, blocks_total = 0, outb = 0;
             for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) {
-                const uint32_t nb = (uint32_t)(Lq / L.band_k[b]), pairs = nb / 2;
-                waves += (pairs + 63) / 64; pairs_total += pairs; outb += round16(26 * nb + 32);
+                const uint32_t nb = (uint32_t)(Lq / L.band_k[b]);
+                waves += (nb + 63) / 64; blocks_total += nb; outb += round16(26 * nb + 32);
             }
             if (waves > (uint32_t)kMaxWaves) break;
-            const uint32_t groups = (uint32_t)(9 * Lq / GS) + 3, stage = groups * GB + 32;
-            const uint32_t total = round16(lut_bytes) + round16((uint32_t)(9 * Lq)) + 16 + std::max(round16(stage), outb);
+            const uint32_t groups = (uint32_t)(9 * Lq / GS) + 3, stage = groups * GB + 1024 + 32;   // +1 KiB: LDS-DMA pieces are whole
+            const uint32_t total = kLdsHdr + round16(lut_bytes) + round16((uint32_t)(9 * Lq)) + 16 + 2 * std::max(round16(stage), outb);
             if (total > budget) break;
-            const double util = (double)pairs_total / (64.0 * waves);
+            const double util = (double)blocks_total / (64.0 * waves);
             const double score = util + 1e-7 * (double)Lq;          // utilisation first, then the larger tile
             if (score > best_score) { best_score = score; best_q = q; }
         }
@@ -108,7 +109,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     if (!best_q) return false;
     const uint32_t Lq = (uint32_t)(Lk * best_q);
     a.Lq = Lq; a.lut_bytes = round16(lut_bytes);
-    uint32_t off = a.lut_bytes;
+    uint32_t off = kLdsHdr + a.lut_bytes;
     a.sym_off = off; off += round16(9 * Lq) + 16;
     a.stage_off = off;
     a.stage_groups = 9 * Lq / GS + 3;
@@ -116,15 +117,16 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     for (int b = 0; b < 9; ++b) {
         a.band_k[b] = L.band_k[b]; a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b];
         a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6);
-        a.band_lut_off[b] = lut.k_off[k_index(L.band_k[b])];
+        a.band_lut_off[b] = kLdsHdr + lut.k_off[k_index(L.band_k[b])];
         if (!(band_mask >> b & 1)) { a.band_nb_tile[b] = 0; a.band_blocks[b] = 0; continue; }
-        const uint32_t nb = Lq / L.band_k[b], pairs = nb / 2;
-        a.band_nb_tile[b] = nb; a.band_out_off[b] = a.stage_off + outb; outb += round16(26 * nb + 32);
-        for (uint32_t w = 0; w < (pairs + 63) / 64; ++w) { a.wave_band[nw] = b; a.wave_pair0[nw] = 64 * w; ++nw; }
+        const uint32_t nb = Lq / L.band_k[b];
+        a.band_nb_tile[b] = nb; a.band_out_off[b] = outb; outb += round16(26 * nb + 32);
+        for (uint32_t w = 0; w < (nb + 63) / 64; ++w) { a.wave_band[nw] = b; a.wave_blk0[nw] = 64 * w; ++nw; }
         n_tiles = std::max<uint32_t>(n_tiles, (uint32_t)((L.band_blocks[b] + nb - 1) / nb));
     }
     a.n_waves = nw; a.n_tiles = n_tiles;
-    a.lds_bytes = a.stage_off + std::max(round16(a.stage_groups * GB + 32), outb);
+    a.stage_stride = std::max(round16(a.stage_groups * GB + 1024 + 32), outb);
+    a.lds_bytes = a.stage_off + 2 * a.stage_stride;
     a.n_sym = (uint32_t)L.n_sym;
     const ScrCycle sc = scrambler_cycle(cfg.seed_a, cfg.seed_b, cfg.seed_s0);
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
@@ -135,18 +137,56 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
         a.div_A = to_dev(fastdiv(a.il_A)); a.div_w = to_dev(fastdiv(a.il_w));
     }
     out.block = 64u * std::max<uint32_t>(nw, 4u);
-    const uint32_t by_lds = std::max<uint32_t>(1u, (160u * 1024u) / a.lds_bytes), by_waves = std::max<uint32_t>(1u, 32u / (out.block / 64u));
-    out.grid = std::max<uint32_t>(1u, std::min<uint32_t>(n_tiles, (uint32_t)g.n_cu * std::min(by_lds, by_waves)));
+    out.rsel = 0;
+    { int k0 = 0; bool same = true; for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) { if (!k0) k0 = L.band_k[b]; else if (k0 != L.band_k[b]) same = false; } if (same && k0) out.rsel = 26 - k0; }
     return true;
 }
 
-template <int FE> int launch_enc(const EncLaunch& e, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) { HIPCHK(hipFuncSetAttribute((const void*)encode_kernel<FE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; }
-    hipLaunchKernelGGL(encode_kernel<FE>, dim3(e.grid), dim3(e.block), e.a.lds_bytes, s, e.a);
-    HIPCHK(hipGetLastError());
+int launch_fn(const void* fn, const EncLaunch& e, hipStream_t s) {
+    // persistent grid = what is actually resident: workgroups/CU from the occupancy query (VGPR, LDS and wave limits)
+    static std::map<std::pair<const void*, uint64_t>, int> occ_cache;
+    const auto key = std::make_pair(fn, (uint64_t)e.block << 32 | e.a.lds_bytes);
+    auto it = occ_cache.find(key);
+    if (it == occ_cache.end()) {
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int occ = 1;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)e.block, e.a.lds_bytes));
+        it = occ_cache.emplace(key, std::max(1, occ)).first;
+    }
+    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(e.a.n_tiles, (uint32_t)(g.n_cu * it->second)));
+#ifdef T3_STAMPS
+    static uint64_t* d_dbg = nullptr; static int calls = 0;
+    if (!d_dbg) HIPCHK(hipMalloc((void**)&d_dbg, 8 * 8 * 4096));
+    HIPCHK(hipMemsetAsync(d_dbg, 0, 8 * 8 * 4096, s));
+    const_cast<EncLaunch&>(e).a.dbg = d_dbg;
+#endif
+    void* args[] = {(void*)&e.a};
+    HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(e.block), args, e.a.lds_bytes, s));
+#ifdef T3_STAMPS
+    if (++calls == 8) {                                     // one report, after warm-up
+        std::vector<uint64_t> h(8 * grid);
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (uint32_t w = 0; w < grid; ++w) for (int i = 0; i < 6; ++i) acc[i] += (double)h[8 * w + i];
+        fprintf(stderr, "[t3 stamps] grid=%u tiles=%u  mean cycles/WG: stage=%.0f p1=%.0f p2=%.0f p3=%.0f total=%.0f  clock=%.3f GHz\n", grid, e.a.n_tiles,
+                acc[0] / grid, acc[1] / grid, acc[2] / grid, acc[3] / grid, acc[4] / grid, acc[4] / acc[5] * 0.1);
+    }
+#endif
     return T3_OK;
 }
+template <int FE, bool IL> int launch_enc2(const EncLaunch& e, hipStream_t s) {
+    const void* fn = (const void*)encode_kernel_mixed<FE, IL>;
+    if (e.block <= 640) switch (e.rsel) {                      // single-k launches use the leaner 640-thread kernels
+        case 2: fn = (const void*)encode_kernel_k<FE, IL, 2>; break;
+        case 4: fn = (const void*)encode_kernel_k<FE, IL, 4>; break;
+        case 6: fn = (const void*)encode_kernel_k<FE, IL, 6>; break;
+        case 8: fn = (const void*)encode_kernel_k<FE, IL, 8>; break;
+        default: break;
+    }
+    return launch_fn(fn, e, s);
+}
+template <int FE> int launch_enc(const EncLaunch& e, hipStream_t s) { return e.a.il_on ? launch_enc2<FE, true>(e, s) : launch_enc2<FE, false>(e, s); }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
@@ -165,7 +205,7 @@ int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, vo
         return T3_OK;
     }
     std::lock_guard<std::mutex> lk(g.mu);
-    uint8_t hdr[84]; memset(hdr, 0, sizeof hdr);
+    uint8_t hdr[96]; memset(hdr, 0, sizeof hdr);
     const uint32_t hs = (uint32_t)header_encode(*cfg, n_raw, hdr);
     const uint32_t pad = (uint32_t)(9 * L.out_words - L.out_syms);
     uint8_t* body_out = (uint8_t*)d_out + hs; uint8_t* frame_out = (uint8_t*)d_out;

@@ -44,7 +44,7 @@ int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_r
     } else {
         t3_layout L; int rc = plan(n_raw, cfg, L); if (rc) return T3_E_HEADER;
         if (L.out_words > n_in) return T3_E_HEADER;                      // truncated stream
-        a.hdr_syms = 81; a.n_sym = L.n_sym;
+        a.hdr_syms = 90; a.n_sym = L.n_sym;
         for (int b = 0; b < 9; ++b) { a.band_k[b] = L.band_k[b]; a.band_blocks[b] = L.band_blocks[b]; a.band_first[b] = total; a.band_off[b] = L.band_body_off[b]; total += L.band_blocks[b]; }
         use_syms = L.n_sym; n_words = n_raw;
     }
@@ -68,9 +68,9 @@ int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_r
 }
 
 int read_header(const void* d_in, uint64_t n_in, int mode, t3_cfg* seen, uint64_t* n_raw, uint8_t next[3], hipStream_t s) {
-    const uint64_t hw = mode == T3_MODE_FIXED ? 9 : 6;
+    const uint64_t hw = mode == T3_MODE_FIXED ? 10 : 6;
     if (n_in < hw) return T3_E_HEADER;                                     // OLD:920
-    uint8_t h[81];
+    uint8_t h[96];
     HIPCHK(hipMemcpyAsync(h, d_in, hw * 9, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return header_parse(h, n_in, mode, *seen, n_raw, next);

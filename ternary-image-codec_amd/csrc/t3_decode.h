@@ -15,7 +15,7 @@ struct DecArgs {
     uint32_t* fail;              // incremented per uncorrectable block (decode_block false, OLD:987)
     const RsTables* tab;
     uint32_t fixed;              // 0 COMPAT framing + Forney add; 1 v6c framing + Forney sub
-    uint32_t hdr_syms;           // 54 (six words, OLD:920-924) / 81
+    uint32_t hdr_syms;           // 54 (six words, OLD:920-924) / 90
     uint32_t band_k[9];
     uint64_t band_blocks[9];
     uint64_t band_first[9];      // prefix sum of band_blocks (work item -> band)

@@ -8,10 +8,11 @@ namespace t3 {
 enum FrontEnd : int { FE_PIXELS = 0, FE_WORDS = 1 };
 
 constexpr int kMaxWaves = 16;            // 1024-thread workgroup
-constexpr int kGroupSyms = 52;           // symbols one phase-1 lane produces from pixels: 12 px = 72 B -> 52 symbols
-constexpr int kGroupPx = 12;
-constexpr int kGroupSymsW = 104;         // from raw words: 12 words = 108 B -> 104 symbols
-constexpr int kGroupWords = 12;
+constexpr int kLdsHdr = 512;            // LDS header: 9 band rows (32 B) + wave roles
+constexpr int kGroupSyms = 26;           // symbols one phase-1 lane produces from pixels: 6 px = 36 B -> 26 symbols
+constexpr int kGroupBytes = 36;
+constexpr int kGroupSymsW = 52;          // from raw words: 6 words = 54 B -> 52 symbols
+constexpr int kGroupBytesW = 54;
 
 struct DevDiv { uint32_t mul, sh, d; };
 
@@ -31,20 +32,22 @@ struct EncArgs {
     uint32_t  band_nb_tile[9];      // blocks per tile
     uint32_t  band_blocks[9];       // blocks in the frame
     uint32_t  band_lut_off[9];      // LDS byte offset of the band's LUT
-    uint32_t  band_out_off[9];      // LDS byte offset of the band's staging run (16-B aligned, 16 B slack)
+    uint32_t  band_out_off[9];      // byte offset of the band's staging run inside the current stage buffer (16-B aligned, slack)
     uint32_t  band_boff6[9];        // (band_body_off + 4) % 6 : scrambler cycle phase of the band's first symbol
     uint64_t  band_body_off[9];
     uint32_t  wave_band[kMaxWaves]; // phase-2 role of each wave: band ...
-    uint32_t  wave_pair0[kMaxWaves];// ... and first block-pair it covers
+    uint32_t  wave_blk0[kMaxWaves]; // ... and first tile-local block it covers (one block per lane)
     uint32_t  n_waves;
-    uint32_t  sym_off, stage_off, lds_bytes;   // LDS carve-up (stage and out staging share one region)
-    uint32_t  stage_groups;         // capacity of the input staging region, in lane groups
+    uint32_t  sym_off, stage_off, lds_bytes;   // LDS carve-up: [hdr][LUT][symbols][stage 0][stage 1]
+    uint32_t  stage_stride;         // bytes between the two input stage buffers (out staging aliases the current one)
+    uint32_t  stage_groups;         // capacity of one input stage buffer, in lane groups
     uint32_t  cyc24; uint32_t pre0, pre1;      // scrambler: 6-periodic tail as 2-bit fields (x2), two pre-period states
     uint32_t  il_on, il_w, il_A;    // 2-D boustrophedon: row width, chunk area (clamped to n_sym)
     DevDiv    div_A, div_w;
     uint32_t  hdr_syms; uint32_t pad_bytes;    // header symbols; zero bytes after the last symbol (OLD:1164-1167)
     uint64_t  out_syms;
-    uint8_t   hdr[84];
+    uint8_t   hdr[96];
+    uint64_t* dbg;                  // diagnostic stamp builds only (T3_STAMPS); null in the product
 };
 
 // beacon insertion pass (OLD:1118-1141): framed[q] = beacon | body[q - #beacons before q] | 0
@@ -52,7 +55,7 @@ struct BeaconArgs {
     const uint8_t* body; uint8_t* frame_out;
     uint64_t body_syms, framed_syms;
     uint32_t period, slot, sym, hdr_syms, pad_bytes;
-    uint8_t  hdr[84];
+    uint8_t  hdr[96];
 };
 
 }  // namespace t3

@@ -268,8 +268,8 @@ int header_encode(const t3_cfg& cin, uint64_t n_raw, uint8_t* out) {
         memcpy(blk, hp, 18);                               memcpy(out, blk, 18);      parity_fixed(18, blk, out + 18);
         memcpy(blk, hp + 18, 9); memcpy(blk + 9, ext, 9);  memcpy(out + 26, blk, 18); parity_fixed(18, blk, out + 44);
         memcpy(blk, ext + 9, 18);                          memcpy(out + 52, blk, 18); parity_fixed(18, blk, out + 70);
-        out[78] = out[79] = out[80] = 0;
-        return 81;
+        memset(out + 78, 0, 12);                           // 10 whole words: the body starts word- and 2-byte-aligned
+        return 90;
     }
     header_pack(cin, 0, 0, hp);                            // frame_seq / band_map_hash are never set by the encoder (OLD:1142-1150)
     rs_generator(18, g);
@@ -281,7 +281,7 @@ int header_encode(const t3_cfg& cin, uint64_t n_raw, uint8_t* out) {
 int header_parse(const uint8_t* w, uint64_t n_words, int mode, t3_cfg& seen, uint64_t* n_raw, uint8_t next[3]) {
     const bool fixed = mode == T3_MODE_FIXED;
     const int nblk = fixed ? 3 : 2;
-    if (n_words < (uint64_t)(fixed ? 9 : 6)) return T3_E_HEADER;        // OLD:920
+    if (n_words < (uint64_t)(fixed ? 10 : 6)) return T3_E_HEADER;        // OLD:920
     uint8_t blk[3][26];
     for (int q = 0; q < nblk; ++q) {
         for (int i = 0; i < 26; ++i) blk[q][i] = w[26 * q + i] % 27;     // symbols >= 27 are UB in the reference; reduced here
@@ -298,6 +298,9 @@ int header_parse(const uint8_t* w, uint64_t n_words, int mode, t3_cfg& seen, uin
         if (n_raw) *n_raw = 0;
         return T3_OK;
     }
+    // the 27-symbol header packs each band triple most-significant-first but unpacks it least-significant-first
+    // (OLD:222-224 vs 327-340); v6c keeps the reference's pack and undoes the reversal here
+    for (int g3 = 0; g3 < 3; ++g3) { const uint8_t t = seen.band_profile[3 * g3]; seen.band_profile[3 * g3] = seen.band_profile[3 * g3 + 2]; seen.band_profile[3 * g3 + 2] = t; }
     uint8_t e[27]; memcpy(e, blk[1] + 9, 9); memcpy(e + 9, blk[2], 18);
     uint32_t v = 0; uint64_t q = 0;
     for (int i = 2; i >= 0; --i) v = v * 27 + e[i];
@@ -331,7 +334,7 @@ int plan(uint64_t W, const t3_cfg& c, t3_layout& L) {
     }
     L.n_sym = (26 * W + 2) / 3;                                         // OLD:1051-1082 (last symbol zero-padded)
     L.interleave2d = want_interleave(c) ? 1 : 0;
-    L.header_syms = fixed ? 81 : 52;
+    L.header_syms = fixed ? 90 : 52;
     uint64_t off = 0;
     for (int b = 0; b < 9; ++b) {
         const uint64_t k = (uint64_t)k_of_band_profile(c.band_profile[b]);

@@ -65,9 +65,9 @@ void crc12(const uint8_t* trits, int n, uint8_t out[12]);
 void header_pack(const t3_cfg& c, uint32_t frame_seq, uint32_t band_map_hash, uint8_t s[27]);
 bool header_check(const uint8_t s[27]);
 void header_unpack(const uint8_t s[27], t3_cfg& out, uint32_t* frame_seq, uint32_t* band_map_hash);
-// coded header in front of the body: COMPAT 52 symbols (OLD:1142-1162), FIXED 81
-int  header_encode(const t3_cfg& c, uint64_t n_raw_words, uint8_t* out /*>=81*/);
-// parse the first 6 (COMPAT) / 9 (FIXED) words of a coded stream. Returns T3_OK or T3_E_HEADER; on success
+// coded header in front of the body: COMPAT 52 symbols (OLD:1142-1162), FIXED 90
+int  header_encode(const t3_cfg& c, uint64_t n_raw_words, uint8_t* out /*>=90*/);
+// parse the first 6 (COMPAT) / 10 (FIXED) words of a coded stream. Returns T3_OK or T3_E_HEADER; on success
 // `seen` is overwritten as OLD:1006-1013 does and (FIXED) *n_raw and next[] are filled.
 int  header_parse(const uint8_t* words, uint64_t n_words, int mode, t3_cfg& seen, uint64_t* n_raw, uint8_t next[3]);
 uint8_t beacon_symbol(uint8_t profile, uint16_t frame_seq_mod, uint8_t health);   // OLD:107-113

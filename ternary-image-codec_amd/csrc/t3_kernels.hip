@@ -19,52 +19,69 @@ extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, const DevDiv& d) { return d.d <= 1 ? n : (__umulhi(n, d.mul) >> d.sh); }
 
 // ---------------------------------------------------------------------------------------------------------
-// symbol construction
+// small-integer division by powers of three with full-rate 24-bit multiplies (ranges checked in tests/test_host_logic.py)
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t div3(uint32_t x)  { return __umul24(x, 171u) >> 9; }    // x < 512
+__device__ __forceinline__ uint32_t div9(uint32_t x)  { return __umul24(x, 228u) >> 11; }   // x < 512
+__device__ __forceinline__ uint32_t div27(uint32_t x) { return __umul24(x, 152u) >> 12; }   // x < 512
+__device__ __forceinline__ uint32_t div81(uint32_t x) { return __umul24(x, 405u) >> 15; }   // x < 885
+__device__ __forceinline__ uint32_t mod3(uint32_t x)  { return x - 3u * div3(x); }
+__device__ __forceinline__ uint32_t mod9(uint32_t x)  { return x - 9u * div9(x); }
+__device__ __forceinline__ uint32_t mod27(uint32_t x) { return x - 27u * div27(x); }
+
 // Components as the reference's i2tr sees them: v % 3^w of the uint32 cast (no clamping, OLD:675-682,697-702).
-__device__ __forceinline__ uint32_t red_y(uint32_t y16) { return y16 % 243u; }
-__device__ __forceinline__ uint32_t red_c(uint32_t c16) { return (uint32_t)((int32_t)(int16_t)c16 + 40) % 81u; }
+// 16-bit operands: floor(x/d) = floor((x + 0.5) * fl(1/d)) exactly for x < 65536 (the +0.5 keeps the product
+// >= 0.5/d away from every integer, far more than the float rounding error).
+__device__ __forceinline__ uint32_t red_y(uint32_t y16) {
+    const uint32_t q = (uint32_t)(((float)y16 + 0.5f) * (1.0f / 243.0f));
+    return y16 - __umul24(q, 243u);
+}
+__device__ __forceinline__ uint32_t red_c(uint32_t c16) {
+    const int32_t v = (int32_t)(int16_t)c16 + 40;
+    // negative v: (2^32 + v) % 81 = (v + 49 + 81*405) % 81, and v + 32854 > 0 for every int16
+    const uint32_t x = v < 0 ? (uint32_t)(v + 32854) : (uint32_t)v;
+    const uint32_t q = (uint32_t)(((float)x + 0.5f) * (1.0f / 81.0f));
+    return x - __umul24(q, 81u);
+}
 
 // 3 pixels = 39 trits = 13 symbols (trit t of the stream = trit t%13 of pixel t/13; Y:5, Cb+40:4, Cr+40:4).
 // Every symbol is a div/mod-by-power-of-3 splice of at most two components — no per-trit work.
 __device__ __forceinline__ void px3_to_sym13(const uint32_t* c /*9 reduced comps*/, uint32_t* s /*13*/) {
     const uint32_t Y0 = c[0], B0 = c[1], R0 = c[2], Y1 = c[3], B1 = c[4], R1 = c[5], Y2 = c[6], B2 = c[7], R2 = c[8];
-    s[0]  = Y0 % 27u;
-    s[1]  = Y0 / 27u + 9u * (B0 % 3u);
-    s[2]  = B0 / 3u;
-    s[3]  = R0 % 27u;
-    s[4]  = R0 / 27u + 3u * (Y1 % 9u);
-    s[5]  = Y1 / 9u;
-    s[6]  = B1 % 27u;
-    s[7]  = B1 / 27u + 3u * (R1 % 9u);
-    s[8]  = R1 / 9u + 9u * (Y2 % 3u);
-    s[9]  = (Y2 / 3u) % 27u;
-    s[10] = Y2 / 81u + 3u * (B2 % 9u);
-    s[11] = B2 / 9u + 9u * (R2 % 3u);
-    s[12] = R2 / 3u;
+    uint32_t q;
+    q = div27(Y0); s[0] = Y0 - 27u * q;            s[1] = q + 9u * mod3(B0);
+    s[2] = div3(B0);
+    q = div27(R0); s[3] = R0 - 27u * q;            s[4] = q + 3u * mod9(Y1);
+    s[5] = div9(Y1);
+    q = div27(B1); s[6] = B1 - 27u * q;            s[7] = q + 3u * mod9(R1);
+    s[8] = div9(R1) + 9u * mod3(Y2);
+    s[9] = mod27(div3(Y2));
+    s[10] = div81(Y2) + 3u * mod9(B2);
+    s[11] = div9(B2) + 9u * mod3(R2);
+    s[12] = div3(R2);
 }
 
 // 3 raw words (27 canonical symbols, trit 26 of each dropped, OLD:1065-1076) = 78 trits = 26 symbols.
-__device__ __forceinline__ void w3_to_sym26(const uint32_t* c /*27 symbols %27*/, uint32_t* s /*26*/) {
+__device__ __forceinline__ void w3_to_sym26(const uint32_t* c /*27 symbols < 27*/, uint32_t* s /*26*/) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = c[i];
-    s[8] = c[8] % 9u + 9u * (c[9] % 3u);
+    s[8] = mod9(c[8]) + 9u * mod3(c[9]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s[9 + i] = c[9 + i] / 3u + 9u * (c[10 + i] % 3u);
-    s[17] = (c[17] / 3u) % 3u + 3u * (c[18] % 9u);
+    for (int i = 0; i < 8; ++i) s[9 + i] = div3(c[9 + i]) + 9u * mod3(c[10 + i]);
+    s[17] = mod3(div3(c[17])) + 3u * mod9(c[18]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s[18 + i] = c[18 + i] / 9u + 3u * (c[19 + i] % 9u);
+    for (int i = 0; i < 8; ++i) s[18 + i] = div9(c[18 + i]) + 3u * mod9(c[19 + i]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K1 / K5 : RAW packer (2 pixels <-> 9 symbols).  One lane = 4 words = 8 pixels = 48 B <-> 36 B.
+// K1 / K5 : RAW packer (2 pixels <-> 9 symbols), one lane per word
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void px2_to_word(const uint32_t* c /*6 reduced comps*/, uint32_t* s /*9*/) {
     // T[0..4]=Ya T[5..8]=Cba T[9..12]=Cra T[13..17]=Yb T[18..21]=Cbb T[22..25]=Crb T[26]=0 (OLD:693-705)
     const uint32_t Y0 = c[0], B0 = c[1], R0 = c[2], Y1 = c[3], B1 = c[4], R1 = c[5];
-    s[0] = Y0 % 27u; s[1] = Y0 / 27u + 9u * (B0 % 3u); s[2] = B0 / 3u; s[3] = R0 % 27u;
-    s[4] = R0 / 27u + 3u * (Y1 % 9u); s[5] = Y1 / 9u; s[6] = B1 % 27u; s[7] = B1 / 27u + 3u * (R1 % 9u);
-    s[8] = R1 / 9u;
+    s[0] = mod27(Y0); s[1] = div27(Y0) + 9u * mod3(B0); s[2] = div3(B0); s[3] = mod27(R0);
+    s[4] = div27(R0) + 3u * mod9(Y1); s[5] = div9(Y1); s[6] = mod27(B1); s[7] = div27(B1) + 3u * mod9(R1);
+    s[8] = div9(R1);
 }
 
 __global__ __launch_bounds__(256) void pack_pixels_kernel(const uint16_t* __restrict__ px, uint64_t n_px, uint8_t* __restrict__ words, uint64_t n_words) {
@@ -87,14 +104,14 @@ __global__ __launch_bounds__(256) void unpack_words_kernel(const uint8_t* __rest
     if (w >= n_words) return;
     uint32_t c[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) c[i] = words[9 * w + i] % 27u;            // unpack3 reduces each digit (OLD:28-31)
+    for (int i = 0; i < 9; ++i) c[i] = mod27(words[9 * w + i]);           // unpack3 reduces each digit (OLD:28-31)
     // inverse of px2_to_word; trit 26 (= c[8]/9) is ignored (OLD:716-721)
-    const uint32_t Y0 = c[0] + 27u * (c[1] % 9u);
-    const uint32_t B0 = c[1] / 9u + 3u * c[2];
-    const uint32_t R0 = c[3] + 27u * (c[4] % 3u);
-    const uint32_t Y1 = c[4] / 3u + 9u * c[5];
-    const uint32_t B1 = c[6] + 27u * (c[7] % 3u);
-    const uint32_t R1 = c[7] / 3u + 9u * (c[8] % 9u);
+    const uint32_t Y0 = c[0] + 27u * mod9(c[1]);
+    const uint32_t B0 = div9(c[1]) + 3u * c[2];
+    const uint32_t R0 = c[3] + 27u * mod3(c[4]);
+    const uint32_t Y1 = div3(c[4]) + 9u * c[5];
+    const uint32_t B1 = c[6] + 27u * mod3(c[7]);
+    const uint32_t R1 = div3(c[7]) + 9u * mod9(c[8]);
     uint16_t* o = px + 6 * w;
     o[0] = (uint16_t)Y0; o[1] = (uint16_t)(int16_t)((int)B0 - 40); o[2] = (uint16_t)(int16_t)((int)R0 - 40);
     o[3] = (uint16_t)Y1; o[4] = (uint16_t)(int16_t)((int)B1 - 40); o[5] = (uint16_t)(int16_t)((int)R1 - 40);
@@ -112,11 +129,26 @@ __device__ __forceinline__ uint32_t mod3x5(uint32_t x) {
     return x - (t | (t << 1));
 }
 
+#ifndef T3_ENC_CHUNK
+#define T3_ENC_CHUNK 5      // data symbols whose LUT reads may be in flight together
+#endif
 template <int R> struct LutGeo;
-template <> struct LutGeo<2> { static constexpr int SLAB = 384, NDW = 3, SCR_SHIFT = 16; };
-template <> struct LutGeo<4> { static constexpr int SLAB = 512, NDW = 3, SCR_SHIFT = 0; };
-template <> struct LutGeo<6> { static constexpr int SLAB = 512, NDW = 4, SCR_SHIFT = 18; };
-template <> struct LutGeo<8> { static constexpr int SLAB = 768, NDW = 5, SCR_SHIFT = 0; };
+template <> struct LutGeo<2> { static constexpr int SLAB = 384, SCR_SHIFT = 16; };
+template <> struct LutGeo<4> { static constexpr int SLAB = 512, SCR_SHIFT = 0; };
+template <> struct LutGeo<6> { static constexpr int SLAB = 512, SCR_SHIFT = 18; };
+template <> struct LutGeo<8> { static constexpr int SLAB = 768, SCR_SHIFT = 0; };
+
+struct Blk26 { uint32_t w[7]; };
+struct BandRow { uint32_t k, nbt, blocks, lut_off, out_off, boff6; uint64_t body_off; };   // 32 B, LDS header row b
+__device__ __forceinline__ BandRow band_row(uint32_t b) { return *(const BandRow*)(lds + 32u * b); }
+__device__ __forceinline__ uint32_t wave_role(uint32_t wave, uint32_t f) { return *(const uint32_t*)(lds + 288u + 8u * wave + 4u * f); }   // 26 output bytes, little-endian packed (w[6] holds 2)
+
+__device__ __forceinline__ uint32_t add13(uint32_t d, uint32_t s) {   // d + (s,s,s) trit-wise (scramble_symbol OLD:81-87)
+    const uint32_t q1 = div3(d), q2 = div9(d);
+    uint32_t t0 = d - 3u * q1 + s, t1 = q1 - 3u * q2 + s, t2 = q2 + s;
+    t0 -= t0 >= 3u ? 3u : 0u; t1 -= t1 >= 3u ? 3u : 0u; t2 -= t2 >= 3u ? 3u : 0u;
+    return t0 + 3u * t1 + 9u * t2;
+}
 
 // One RS block: K data symbols read at stride 9 from the stream-ordered LDS symbol buffer, parity through the
 // per-position LUT (two or three conflict-free ds_read_b64 per symbol), scrambling folded into the same reads.
@@ -124,82 +156,76 @@ template <> struct LutGeo<8> { static constexpr int SLAB = 768, NDW = 5, SCR_SHI
 //   lut      : LDS byte address of the band's LUT
 //   c0       : scrambler cycle phase of the block's first body symbol ((i0 - 2) mod 6)
 //   first    : block starts at body symbol 0 (the two pre-period states apply)
-//   o[7]     : 26 output bytes, little-endian packed (o[6] holds 2)
 template <int R>
-__device__ __forceinline__ void encode_block(uint32_t sym_addr, uint32_t lut, uint32_t c0, bool first, const EncArgs& a, uint32_t* o) {
+__device__ __forceinline__ Blk26 encode_block(uint32_t sym_addr, uint32_t lut, uint32_t c0, bool first, const EncArgs& a) {
     constexpr int K = 26 - R;
     using G = LutGeo<R>;
-    // scrambler state per residue class of the position (cycle is 6-periodic)
-    uint32_t st[6], sh[6];
+    uint32_t st[6], sh[6];                          // scrambler state per residue class of the position (6-periodic)
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         st[q] = (a.cyc24 >> (2u * (c0 + q))) & 3u;
         sh[q] = (uint32_t)G::SCR_SHIFT + 5u * (st[q] >> 1);   // T1 at SCR_SHIFT, T2 at SCR_SHIFT+5; unused when st==0
     }
-    uint32_t acc[5] = {0, 0, 0, 0, 0};
+    uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0;
+    Blk26 o;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) o[i] = 0;
-    uint32_t d01[2] = {0, 0};
+    for (int i = 0; i < 7; ++i) o.w[i] = 0;
+    uint32_t d0 = 0, d1 = 0;
 #pragma unroll
     for (int p = 0; p < K; ++p) {
         const uint32_t d = lds[sym_addr + 9 * p];
-        if (p < 2) d01[p] = d;
+        if (p == 0) d0 = d;
+        if (p == 1) d1 = d;
         const uint32_t e = lut + (uint32_t)(p * G::SLAB) + d * 8u;
         const uint2 A = *(const uint2*)(lds + e);
-        acc[0] += A.x; acc[1] += A.y;
+        acc0 += A.x; acc1 += A.y;
         uint32_t scr;
         if constexpr (R == 2) {
             const uint32_t B = *(const uint32_t*)(lds + lut + (uint32_t)(p * G::SLAB) + 256u + d * 4u);
-            acc[2] += B; scr = B;
+            acc2 += B; scr = B;
         } else {
             const uint2 B = *(const uint2*)(lds + e + 256u);
-            acc[2] += B.x;
-            if constexpr (R == 4) scr = B.y;
-            if constexpr (R == 6) { acc[3] += B.y; scr = B.y; }
-            if constexpr (R == 8) {
-                acc[3] += B.y;
-                const uint2 C = *(const uint2*)(lds + e + 512u);
-                acc[4] += C.x; scr = C.y;
-            }
+            acc2 += B.x; scr = B.y;
+            if constexpr (R >= 6) acc3 += B.y;
+            if constexpr (R == 8) { const uint2 C = *(const uint2*)(lds + e + 512u); acc4 += C.x; scr = C.y; }
         }
         const uint32_t v = (scr >> sh[p % 6]) & 31u;
         const uint32_t outp = st[p % 6] == 0 ? d : v;
-        o[p >> 2] |= outp << (8 * (p & 3));
+        o.w[p >> 2] |= outp << (8 * (p & 3));
+        if (p % T3_ENC_CHUNK == T3_ENC_CHUNK - 1) {
+            // bound the LUT reads in flight: without this the compiler issues all K*2 reads first and sinks the adds,
+            // which costs ~4 VGPRs per symbol and spills
+            asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "+v"(acc4), "+v"(o.w[p >> 2]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // parity symbols get their own scrambler states: add them to the trit fields before the mod-3 fold
     constexpr int NMAIN = R < 5 ? R : 5;
     uint32_t cm = 0;
 #pragma unroll
     for (int j = 0; j < NMAIN; ++j) cm |= st[(K + j) % 6] << (6 * j);
-    const uint32_t x0 = mod3x5(acc[0] + cm), x1 = mod3x5(acc[1] + cm), x2 = mod3x5(acc[2] + cm);
+    const uint32_t x0 = mod3x5(acc0 + cm), x1 = mod3x5(acc1 + cm), x2 = mod3x5(acc2 + cm);
     const uint32_t S = x0 + 3u * x1 + 9u * x2;           // five parity symbols in 6-bit fields
     uint32_t par[8];
 #pragma unroll
     for (int j = 0; j < NMAIN; ++j) par[j] = (S >> (6 * j)) & 63u;
     if constexpr (R == 6) {
-        const uint32_t x3 = mod3x5(acc[3] + st[(K + 5) % 6] * 0x1041u);
+        const uint32_t x3 = mod3x5(acc3 + st[(K + 5) % 6] * 0x1041u);
         par[5] = (x3 & 63u) + 3u * ((x3 >> 6) & 63u) + 9u * ((x3 >> 12) & 63u);
     }
     if constexpr (R == 8) {
         const uint32_t s5 = st[(K + 5) % 6], s6 = st[(K + 6) % 6], s7 = st[(K + 7) % 6];
-        const uint32_t x3 = mod3x5(acc[3] + s5 * 0x1041u + s6 * 0x1040000u);
-        const uint32_t x4 = mod3x5(acc[4] + s6 + s7 * 0x41040u);
+        const uint32_t x3 = mod3x5(acc3 + s5 * 0x1041u + s6 * 0x1040000u);
+        const uint32_t x4 = mod3x5(acc4 + s6 + s7 * 0x41040u);
         par[5] = (x3 & 63u) + 3u * ((x3 >> 6) & 63u) + 9u * ((x3 >> 12) & 63u);
         par[6] = ((x3 >> 18) & 63u) + 3u * ((x3 >> 24) & 63u) + 9u * (x4 & 63u);
         par[7] = ((x4 >> 6) & 63u) + 3u * ((x4 >> 12) & 63u) + 9u * ((x4 >> 18) & 63u);
     }
 #pragma unroll
-    for (int j = 0; j < R; ++j) { const int p = K + j; o[p >> 2] |= par[j] << (8 * (p & 3)); }
-    if (first) {
-        // body symbols 0 and 1 see the pre-period states (exact whatever the seed; OLD:81-87)
-        const uint32_t pre[2] = {a.pre0, a.pre1};
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const uint32_t d = d01[p], s = pre[p];
-            const uint32_t t0 = (d % 3u + s) % 3u, t1 = ((d / 3u) % 3u + s) % 3u, t2 = (d / 9u + s) % 3u;
-            o[0] = (o[0] & ~(0xFFu << (8 * p))) | ((t0 + 3u * t1 + 9u * t2) << (8 * p));
-        }
-    }
+    for (int j = 0; j < R; ++j) { const int p = K + j; o.w[p >> 2] |= par[j] << (8 * (p & 3)); }
+    if (first)   // body symbols 0 and 1 see the pre-period states (exact whatever the seed; OLD:81-87)
+        o.w[0] = (o.w[0] & 0xFFFF0000u) | add13(d0, a.pre0) | (add13(d1, a.pre1) << 8);
+    return o;
 }
 
 // 2-D boustrophedon position map (an involution inside each row segment; OLD:750-780)
@@ -221,164 +247,249 @@ __device__ __forceinline__ uint32_t il_row_end(uint32_t u, const EncArgs& a) {  
     return base + r * a.il_w + min(a.il_w, take - r * a.il_w);
 }
 
+template <int R>
+__device__ __forceinline__ void phase2_band(const EncArgs& a, uint32_t stage, uint32_t tile, uint32_t b, uint32_t m, uint32_t nbt, uint32_t lane) {
+    constexpr uint32_t K = 26 - R;
+    const uint32_t mg = tile * nbt + m;
+    const BandRow r = band_row(b);
+    const bool valid = m < nbt && mg < r.blocks;
+    Blk26 o;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) o.w[i] = 0;
+    if (valid) {
+        const uint32_t c0 = (r.boff6 + 2u * (mg % 3u)) % 6u;                         // 26 == 2 (mod 6)
+        o = encode_block<R>(a.sym_off + b + 9u * K * m, r.lut_off, c0, r.body_off == 0 && mg == 0, a);
+    }
+    // The staging image is placed so that LDS address == global address (mod 16): the copy-out is then aligned on both
+    // sides.  Block starts are only 2-byte aligned, so every lane stores the 7 aligned dwords that cover its 26 bytes and
+    // takes the 2 bytes it shares with its neighbour through a lane shuffle (both lanes store the same value there).
+    const uint32_t nxt0 = __shfl_down(o.w[0], 1), prv6 = __shfl_up(o.w[6], 1);
+    if (!valid) return;
+    const uint64_t gaddr = (uint64_t)(uintptr_t)a.body_out + r.body_off + 26ull * ((uint64_t)tile * nbt);
+    const uint32_t off = stage + r.out_off + ((uint32_t)gaddr & 15u) + 26u * m;
+    const bool al = (off & 2u) == 0;
+    const uint32_t A0 = off & ~3u;
+    uint32_t D[7];
+    D[0] = al ? o.w[0] : ((prv6 & 0xFFFFu) | (o.w[0] << 16));
+#pragma unroll
+    for (int i = 1; i < 6; ++i) D[i] = al ? o.w[i] : ((o.w[i - 1] >> 16) | (o.w[i] << 16));
+    D[6] = al ? ((o.w[6] & 0xFFFFu) | (nxt0 << 16)) : ((o.w[5] >> 16) | (o.w[6] << 16));
+#pragma unroll
+    for (int i = 1; i < 6; ++i) *(uint32_t*)(lds + A0 + 4 * i) = D[i];
+    if (al || lane > 0) *(uint32_t*)(lds + A0) = D[0]; else *(uint16_t*)(lds + A0 + 2) = (uint16_t)(D[0] >> 16);
+    if (!al || lane < 63) *(uint32_t*)(lds + A0 + 24) = D[6]; else *(uint16_t*)(lds + A0 + 24) = (uint16_t)D[6];
+}
+
+// Stage the input bytes of lane groups [g_lo, g_hi) into the stage buffer at LDS offset `stage`: image byte x = input
+// byte b0 + x with b0 = 16-aligned start of group g_lo.  Whole 1-KiB pieces inside the real data go by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, completes behind vmcnt, so the next tile's input streams in under
+// this tile's compute); pieces that touch the end of the data are synthesised (pad pixel OLD:730, then zero trits).
 template <int FE>
-__global__ __launch_bounds__(1024) void encode_kernel(const EncArgs a) {
+__device__ __forceinline__ void stage_input(const EncArgs& a, uint32_t stage, uint32_t g_lo, uint32_t g_hi, uint32_t lane, uint32_t wave, uint32_t nwv) {
+    constexpr uint32_t GB = FE == FE_PIXELS ? kGroupBytes : kGroupBytesW, UB = FE == FE_PIXELS ? 6u : 9u;
+    const uint64_t b0 = ((uint64_t)g_lo * GB) & ~15ull, b1 = (uint64_t)g_hi * GB, real = a.n_units * UB;
+    const uint32_t n_chunks = (uint32_t)((b1 - b0 + 15u) >> 4);
+    for (uint32_t c0 = __builtin_amdgcn_readfirstlane(wave) * 64u; c0 < n_chunks; c0 += nwv * 64u) {
+        const uint64_t o = b0 + 16ull * (c0 + lane);
+        if (b0 + 16ull * (c0 + 64u) <= real) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t*)(a.in + o),
+                                             (__attribute__((address_space(3))) uint32_t*)(lds + stage + 16u * c0), 16, 0, 0);
+        } else if (c0 + lane < n_chunks) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (o + 16u <= real) { const uint4 v = *(const uint4*)(a.in + o); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+            else if constexpr (FE == FE_PIXELS) {
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const uint64_t n = (o >> 1) + h, px = n / 3u; const uint32_t comp = (uint32_t)(n - 3u * px);
+                    uint32_t val;
+                    if (px < a.n_units) val = *(const uint16_t*)(a.in + 2u * n);
+                    else if (px < a.n_units_pad) val = 0u;
+                    else val = comp == 0 ? 0u : 0xFFD8u;                          // -40 -> Cb+40 = 0
+                    w[h >> 1] |= val << (16 * (h & 1));
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 16; ++h) { const uint64_t n = o + h; if (n < real) w[h >> 2] |= (uint32_t)a.in[n] << (8 * (h & 3)); }
+            }
+            *(uint4*)(lds + stage + 16u * (c0 + lane)) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
+// Phase 1: lane groups [g_lo, g_hi) of the stage buffer -> stream-ordered symbols [S0, S0+TS) in LDS.
+template <int FE, bool IL>
+__device__ __forceinline__ void convert_groups(const EncArgs& a, uint32_t stage, uint32_t g_base, uint32_t g_lo, uint32_t g_hi,
+                                               uint32_t S0, uint32_t TS, uint32_t tid, uint32_t nthr) {
+    constexpr uint32_t GS = FE == FE_PIXELS ? kGroupSyms : kGroupSymsW, GB = FE == FE_PIXELS ? kGroupBytes : kGroupBytesW;
+    constexpr uint32_t QS = GS / 2;                                        // 3 px -> 13 symbols, 3 words -> 26 symbols
+    constexpr uint32_t EM = FE == FE_PIXELS ? 2u : 4u;                     // bytes per LDS store on the fast path (26 g is 2-aligned)
+    const uint64_t b0 = ((uint64_t)g_base * GB) & ~15ull;
+    for (uint32_t g0 = g_lo; g0 < g_hi; g0 += nthr) {                      // wave-uniform trip count (ballots inside)
+        const uint32_t g = g0 + tid; const bool live = g < g_hi;
+        const uint32_t src = stage + (uint32_t)((uint64_t)(live ? g : g_lo) * GB - b0);
+        const uint32_t u0 = g * GS;
+        const bool whole = !IL && u0 >= S0 && u0 + GS <= S0 + TS;         // whole group lands in the tile: wide stores
+        const uint32_t dst = a.sym_off + (u0 - S0);
+        uint32_t acc = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 2; ++q) {
+            uint32_t sq[QS];
+            if constexpr (FE == FE_PIXELS) {
+                uint32_t h[9], c[9]; bool bad = false;
+#pragma unroll
+                for (uint32_t i = 0; i < 9; ++i) {
+                    h[i] = *(const uint16_t*)(lds + src + 18u * q + 2u * i);
+                    c[i] = (i % 3 == 0) ? h[i] : ((h[i] + 40u) & 0xFFFFu);
+                    bad |= c[i] >= ((i % 3 == 0) ? 243u : 81u);
+                }
+                if (__builtin_amdgcn_ballot_w64(bad) != 0) {                // out-of-range quantised values: exact general reduction
+#pragma unroll
+                    for (uint32_t i = 0; i < 9; ++i) c[i] = (i % 3 == 0) ? red_y(h[i]) : red_c(h[i]);
+                }
+                px3_to_sym13(c, sq);
+            } else {
+                uint32_t c[27]; bool bad = false;
+#pragma unroll
+                for (uint32_t i = 0; i < 27; ++i) { c[i] = lds[src + 27u * q + i]; bad |= c[i] >= 27u; }
+                if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 27; ++i) c[i] = mod27(c[i]);
+                }
+                w3_to_sym26(c, sq);
+            }
+            if (live && whole) {
+#pragma unroll
+                for (uint32_t i = 0; i < QS; ++i) {
+                    const uint32_t n = q * QS + i;
+                    acc |= sq[i] << (8u * (n % EM));
+                    if (n % EM == EM - 1u) {
+                        if constexpr (EM == 2u) *(uint16_t*)(lds + dst + (n - 1u)) = (uint16_t)acc; else *(uint32_t*)(lds + dst + (n - 3u)) = acc;
+                        acc = 0;
+                    }
+                }
+            } else if (live) {
+#pragma unroll
+                for (uint32_t i = 0; i < QS; ++i) {
+                    uint32_t u = u0 + q * QS + i;
+                    if constexpr (IL) { if (u >= a.n_sym) continue; u = il_perm(u, a); }
+                    if (u >= S0 && u < S0 + TS) lds[a.sym_off + (u - S0)] = (uint8_t)sq[i];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// workgroup barrier that waits for this wave's LDS traffic only: unlike __syncthreads() it leaves the LDS-DMA prefetch
+// of the next tile (and the previous tile's global stores) in flight
+__device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ... and the one at the top of a tile, which also drains vmcnt: the prefetched input has landed for every wave
+__device__ __forceinline__ void barrier_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// RSEL = 26-k when every band of the launch shares one k (the common case: no dead code paths, fewer registers,
+// 640-thread bound so that two workgroups share a CU); RSEL = 0 handles mixed k with a wave-uniform switch.
+template <int FE, bool IL, int RSEL>
+__device__ __forceinline__ void encode_body(const EncArgs& a) {
     constexpr uint32_t GS = FE == FE_PIXELS ? kGroupSyms : kGroupSymsW;      // symbols per lane group
-    constexpr uint32_t GB = FE == FE_PIXELS ? 72u : 108u;                     // input bytes per lane group
-    constexpr uint32_t UB = FE == FE_PIXELS ? 6u : 9u;                        // bytes per input unit
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwv = nthr >> 6;
     const uint32_t TS = 9u * a.Lq;
 
-    // LUT images -> LDS once per (persistent) workgroup
+    // per-band geometry and wave roles -> LDS header (kernel arguments must not be indexed dynamically: that would
+    // force a private copy of the whole argument block); LUT images -> LDS once per (persistent) workgroup
+    if (tid == 0) {
+#pragma unroll
+        for (int b = 0; b < 9; ++b) {
+            BandRow r; r.k = a.band_k[b]; r.nbt = a.band_nb_tile[b]; r.blocks = a.band_blocks[b]; r.lut_off = a.band_lut_off[b];
+            r.out_off = a.band_out_off[b]; r.boff6 = a.band_boff6[b]; r.body_off = a.band_body_off[b];
+            *(BandRow*)(lds + 32 * b) = r;
+        }
+#pragma unroll
+        for (int w = 0; w < kMaxWaves; ++w) { *(uint32_t*)(lds + 288 + 8 * w) = a.wave_band[w]; *(uint32_t*)(lds + 292 + 8 * w) = a.wave_blk0[w]; }
+    }
     for (uint32_t i = tid * 16u; i < a.lut_bytes; i += nthr * 16u)
-        *(uint4*)(lds + i) = *(const uint4*)((const uint8_t*)a.lut_img + i);
+        *(uint4*)(lds + kLdsHdr + i) = *(const uint4*)((const uint8_t*)a.lut_img + i);
 
     if (blockIdx.x == 0 && a.frame_out) {                                    // header symbols + zero tail (OLD:1159-1167)
-        if (tid < a.hdr_syms) a.frame_out[tid] = a.hdr[tid];
+        if (tid == 0) {                                                      // constant indices only (see above)
+#pragma unroll
+            for (uint32_t i = 0; i < 96; ++i) if (i < a.hdr_syms) a.frame_out[i] = a.hdr[i];
+        }
         if (tid < a.pad_bytes) a.frame_out[a.out_syms + tid] = 0;
     }
-    __syncthreads();
 
-    for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+#ifdef T3_STAMPS   // diagnostic build: per-phase cycle sums of wave 0 (never in the product build)
+    uint64_t st_acc[4] = {0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime(), st_t0 = st_prev, st_rt0 = __builtin_amdgcn_s_memrealtime();
+#define T3_STAMP(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define T3_STAMP(i) do { } while (0)
+#endif
+
+    uint32_t it = 0;
+    if constexpr (!IL) {                                                     // prologue: first tile's input
+        if (blockIdx.x < a.n_tiles) stage_input<FE>(a, a.stage_off, (blockIdx.x * TS) / GS, (blockIdx.x * TS + TS + GS - 1u) / GS, lane, wave, nwv);
+    }
+    for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x, ++it) {
         const uint32_t S0 = tile * TS;
+        const uint32_t stage = a.stage_off + (IL ? 0u : (it & 1u) * a.stage_stride);
         // ---------------- phase 1: input -> stream-ordered symbols in LDS ----------------
-        uint32_t u_lo = S0, u_hi = S0 + TS;                                   // pre-interleave symbols this tile needs
-        if (a.il_on) {
+        if constexpr (!IL) {
+            barrier_all();                                                    // this tile's input has landed; the other buffer is free
+            T3_STAMP(0);
+            const uint32_t nxt = tile + gridDim.x;
+            if (nxt < a.n_tiles)
+                stage_input<FE>(a, a.stage_off + ((it & 1u) ^ 1u) * a.stage_stride, (nxt * TS) / GS, (nxt * TS + TS + GS - 1u) / GS, lane, wave, nwv);
+#ifndef T3_ABL_NO_P1
+            convert_groups<FE, false>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, tid, nthr);
+#endif
+            barrier_lds();
+            T3_STAMP(1);
+        } else {
+            __syncthreads();                                                  // previous tile's copy-out has read the staging region
             for (uint32_t i = tid * 16u; i < TS; i += nthr * 16u) *(uint4*)(lds + a.sym_off + i) = make_uint4(0, 0, 0, 0);
+            uint32_t u_lo = S0, u_hi = S0;                                   // pre-interleave symbols this tile needs: whole row segments
             const uint32_t hi = min(S0 + TS, a.n_sym);
-            if (S0 < hi) { u_lo = il_row_start(S0, a); u_hi = il_row_end(hi - 1u, a); } else u_hi = u_lo;
+            if (S0 < hi) { u_lo = il_row_start(S0, a); u_hi = il_row_end(hi - 1u, a); }
+            const uint32_t g_lo = u_lo / GS, g_hi = (u_hi + GS - 1u) / GS;
             __syncthreads();
-        }
-        const uint32_t g_lo = u_lo / GS, g_hi = (u_hi + GS - 1u) / GS;
-        for (uint32_t gc = g_lo; gc < g_hi; gc += a.stage_groups) {
-            const uint32_t gc_hi = min(g_hi, gc + a.stage_groups);
-            const uint64_t b0 = ((uint64_t)gc * GB) & ~15ull, b1 = (uint64_t)gc_hi * GB;
-            const uint64_t real = a.n_units * UB;
-            const uint32_t n_chunks = (uint32_t)((b1 - b0 + 15u) >> 4);
-            for (uint32_t i = tid; i < n_chunks; i += nthr) {                  // coalesced 16-B row loads
-                const uint64_t o = b0 + 16ull * i;
-                uint4 v;
-                if (o + 16u <= real) v = *(const uint4*)(a.in + o);
-                else {
-                    uint32_t w[4] = {0, 0, 0, 0};
-                    if constexpr (FE == FE_PIXELS) {
-#pragma unroll
-                        for (int h = 0; h < 8; ++h) {                             // shorts past the data: pad pixel, then zero-trit pixels
-                            const uint64_t n = (o >> 1) + h, px = n / 3u; const uint32_t comp = (uint32_t)(n - 3u * px);
-                            uint32_t val;
-                            if (px < a.n_units) val = *(const uint16_t*)(a.in + 2u * n);
-                            else if (px < a.n_units_pad) val = 0u;
-                            else val = comp == 0 ? 0u : 0xFFD8u;                  // -40 -> Cb+40 = 0
-                            w[h >> 1] |= val << (16 * (h & 1));
-                        }
-                    } else {
-#pragma unroll
-                        for (int h = 0; h < 16; ++h) { const uint64_t n = o + h; if (n < real) w[h >> 2] |= (uint32_t)a.in[n] << (8 * (h & 3)); }
-                    }
-                    v = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-                *(uint4*)(lds + a.stage_off + 16u * i) = v;
+            for (uint32_t gc = g_lo; gc < g_hi; gc += a.stage_groups) {
+                const uint32_t gc_hi = min(g_hi, gc + a.stage_groups);
+                stage_input<FE>(a, stage, gc, gc_hi, lane, wave, nwv);
+                __syncthreads();
+                T3_STAMP(0);
+                convert_groups<FE, true>(a, stage, gc, gc, gc_hi, S0, TS, tid, nthr);
+                __syncthreads();
+                T3_STAMP(1);
             }
-            __syncthreads();
-            for (uint32_t g = gc + tid; g < gc_hi; g += nthr) {
-                const uint32_t src = a.stage_off + (uint32_t)((uint64_t)g * GB - b0);
-                uint32_t s[GS];
-                if constexpr (FE == FE_PIXELS) {
-                    uint32_t raw[18];
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) { const uint2 t = *(const uint2*)(lds + src + 8 * i); raw[2 * i] = t.x; raw[2 * i + 1] = t.y; }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint32_t c[9];
-#pragma unroll
-                        for (int i = 0; i < 9; ++i) {
-                            const int n = 9 * q + i; const uint32_t h = (raw[n >> 1] >> (16 * (n & 1))) & 0xFFFFu;
-                            c[i] = (i % 3 == 0) ? red_y(h) : red_c(h);
-                        }
-                        px3_to_sym13(c, s + 13 * q);
-                    }
-                } else {
-                    uint32_t raw[27];
-#pragma unroll
-                    for (int i = 0; i < 27; ++i) raw[i] = *(const uint32_t*)(lds + src + 4 * i);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint32_t c[27];
-#pragma unroll
-                        for (int i = 0; i < 27; ++i) { const int n = 27 * q + i; c[i] = ((raw[n >> 2] >> (8 * (n & 3))) & 0xFFu) % 27u; }
-                        w3_to_sym26(c, s + 26 * q);
-                    }
-                }
-                const uint32_t u0 = g * GS;
-                if (!a.il_on && u0 >= S0 && u0 + GS <= S0 + TS) {               // whole group lands in the tile: dword stores
-                    const uint32_t dst = a.sym_off + (u0 - S0);
-#pragma unroll
-                    for (uint32_t i = 0; i < GS / 4; ++i)
-                        *(uint32_t*)(lds + dst + 4 * i) = s[4 * i] | s[4 * i + 1] << 8 | s[4 * i + 2] << 16 | s[4 * i + 3] << 24;
-                } else {
-#pragma unroll
-                    for (uint32_t i = 0; i < GS; ++i) {
-                        uint32_t u = u0 + i;
-                        if (a.il_on) { if (u >= a.n_sym) continue; u = il_perm(u, a); }
-                        if (u >= S0 && u < S0 + TS) lds[a.sym_off + (u - S0)] = (uint8_t)s[i];
-                    }
-                }
-            }
-            __syncthreads();
         }
 
-        // ---------------- phase 2: one lane = two consecutive RS blocks of one band ----------------
+        // ---------------- phase 2: one lane = one RS block; a wave stays inside one band ----------------
+#ifndef T3_ABL_NO_P2
         if (wave < a.n_waves) {
-            const uint32_t b = a.wave_band[wave], t = a.wave_pair0[wave] + lane;
-            const uint32_t k = a.band_k[b], nbt = a.band_nb_tile[b];
-            const uint32_t m0 = 2u * t, mg0 = tile * nbt + m0;
-            if (m0 < nbt && mg0 < a.band_blocks[b]) {
-                const uint32_t lut = a.band_lut_off[b];
-                const uint32_t sa = a.sym_off + b + 9u * k * m0;
-                const uint32_t cA = (a.band_boff6[b] + 2u * (mg0 % 3u)) % 6u, cB = (cA + 2u) % 6u;   // 26 == 2 (mod 6)
-                const bool first = (a.band_body_off[b] == 0) && (mg0 == 0);
-                uint32_t oA[7], oB[7];
-                switch (k) {
-                    case 24: encode_block<2>(sa, lut, cA, first, a, oA); encode_block<2>(sa + 9u * 24u, lut, cB, false, a, oB); break;
-                    case 22: encode_block<4>(sa, lut, cA, first, a, oA); encode_block<4>(sa + 9u * 22u, lut, cB, false, a, oB); break;
-                    case 20: encode_block<6>(sa, lut, cA, first, a, oA); encode_block<6>(sa + 9u * 20u, lut, cB, false, a, oB); break;
-                    default: encode_block<8>(sa, lut, cA, first, a, oA); encode_block<8>(sa + 9u * 18u, lut, cB, false, a, oB); break;
-                }
-                uint32_t w13[13];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) w13[i] = oA[i];
-                w13[6] = (oA[6] & 0xFFFFu) | (oB[0] << 16);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) w13[7 + i] = (oB[i] >> 16) | (oB[i + 1] << 16);
-                // staging image is placed so that LDS address == global address (mod 16): the copy-out is then
-                // aligned on both sides.  Global run starts are even, so dword stores are either aligned or off by 2.
-                const uint64_t gaddr = (uint64_t)(uintptr_t)a.body_out + a.band_body_off[b] + 26ull * ((uint64_t)tile * nbt);
-                const uint32_t shift = (uint32_t)gaddr & 15u;
-                const uint32_t dst = a.band_out_off[b] + shift + 52u * t;
-                if ((shift & 2u) == 0) {
-#pragma unroll
-                    for (int i = 0; i < 13; ++i) *(uint32_t*)(lds + dst + 4 * i) = w13[i];
-                } else {
-                    *(uint16_t*)(lds + dst) = (uint16_t)w13[0];
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) *(uint32_t*)(lds + dst + 2 + 4 * i) = (w13[i] >> 16) | (w13[i + 1] << 16);
-                    *(uint16_t*)(lds + dst + 50) = (uint16_t)(w13[12] >> 16);
-                }
+            const uint32_t b = wave_role(wave, 0), m = wave_role(wave, 1) + lane, nbt = band_row(b).nbt;
+            if constexpr (RSEL != 0) phase2_band<RSEL>(a, stage, tile, b, m, nbt, lane);
+            else switch (band_row(b).k) {
+                case 24: phase2_band<2>(a, stage, tile, b, m, nbt, lane); break;
+                case 22: phase2_band<4>(a, stage, tile, b, m, nbt, lane); break;
+                case 20: phase2_band<6>(a, stage, tile, b, m, nbt, lane); break;
+                default: phase2_band<8>(a, stage, tile, b, m, nbt, lane); break;
             }
         }
-        __syncthreads();
+#endif
+        barrier_lds();
+        T3_STAMP(2);
 
         // ---------------- phase 3: coalesced copy-out, one band run per wave ----------------
-        const uint32_t nwv = nthr >> 6;
+#ifndef T3_ABL_NO_P3
         for (uint32_t b = wave; b < 9; b += nwv) {
-            const uint32_t nbt = a.band_nb_tile[b];
+            const BandRow r = band_row(b);
+            const uint32_t nbt = r.nbt;
             const uint64_t first_blk = (uint64_t)tile * nbt;
-            if (first_blk >= a.band_blocks[b]) continue;
-            const uint32_t nvalid = (uint32_t)min((uint64_t)nbt, (uint64_t)a.band_blocks[b] - first_blk);
+            if (first_blk >= r.blocks) continue;
+            const uint32_t nvalid = (uint32_t)min((uint64_t)nbt, (uint64_t)r.blocks - first_blk);
             const uint32_t Rb = 26u * nvalid;
-            uint8_t* g = a.body_out + a.band_body_off[b] + 26ull * first_blk;
+            uint8_t* g = a.body_out + r.body_off + 26ull * first_blk;
             const uint32_t shift = (uint32_t)(uintptr_t)g & 15u;
-            const uint32_t src = a.band_out_off[b] + shift;
+            const uint32_t src = stage + r.out_off + shift;
             const uint32_t head = min(Rb, (16u - shift) & 15u);
             if (2u * lane < head) *(uint16_t*)(g + 2u * lane) = *(const uint16_t*)(lds + src + 2u * lane);
             const uint32_t nmain = (Rb - head) >> 4;
@@ -387,12 +498,31 @@ __global__ __launch_bounds__(1024) void encode_kernel(const EncArgs a) {
             const uint32_t done = head + 16u * nmain, tail = Rb - done;
             if (2u * lane < tail) *(uint16_t*)(g + done + 2u * lane) = *(const uint16_t*)(lds + src + done + 2u * lane);
         }
-        __syncthreads();
+#endif
+        T3_STAMP(3);
     }
+#ifdef T3_STAMPS
+    if (tid == 0 && a.dbg) {
+        uint64_t* d = a.dbg + 8ull * blockIdx.x;
+        d[0] = st_acc[0]; d[1] = st_acc[1]; d[2] = st_acc[2]; d[3] = st_acc[3];
+        d[4] = __builtin_amdgcn_s_memtime() - st_t0; d[5] = __builtin_amdgcn_s_memrealtime() - st_rt0;
+    }
+#endif
 }
 
-template __global__ void encode_kernel<FE_PIXELS>(const EncArgs);
-template __global__ void encode_kernel<FE_WORDS>(const EncArgs);
+#ifndef T3_ENC_WAVES_PER_EU
+#define T3_ENC_WAVES_PER_EU 6   // <= 80 VGPRs: two 9-wave workgroups per CU place 3+3 waves on one SIMD
+#endif
+template <int FE, bool IL, int RSEL>
+__global__ __launch_bounds__(640, T3_ENC_WAVES_PER_EU) void encode_kernel_k(const EncArgs a) { encode_body<FE, IL, RSEL>(a); }
+template <int FE, bool IL>
+__global__ __launch_bounds__(1024) void encode_kernel_mixed(const EncArgs a) { encode_body<FE, IL, 0>(a); }
+
+#define T3_INST_K(FE, IL) \
+    template __global__ void encode_kernel_k<FE, IL, 2>(const EncArgs); template __global__ void encode_kernel_k<FE, IL, 4>(const EncArgs); \
+    template __global__ void encode_kernel_k<FE, IL, 6>(const EncArgs); template __global__ void encode_kernel_k<FE, IL, 8>(const EncArgs); \
+    template __global__ void encode_kernel_mixed<FE, IL>(const EncArgs);
+T3_INST_K(FE_PIXELS, false) T3_INST_K(FE_PIXELS, true) T3_INST_K(FE_WORDS, false) T3_INST_K(FE_WORDS, true)
 
 // ---------------------------------------------------------------------------------------------------------
 // beacon insertion pass (OLD:1118-1141): gather, one lane per framed byte

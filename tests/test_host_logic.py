@@ -116,7 +116,7 @@ def test_layout_and_coded_header(built, orc, mode):
         rc, enc = orc.encode_profile(raw, oc)
         assert rc == 0
         hs = built.header_encode(to_t3(built, oc), len(raw))
-        assert len(hs) == (81 if mode else 52)
+        assert len(hs) == (90 if mode else 52)
         assert np.array_equal(hs, enc.reshape(-1)[: len(hs)])
     L = built.plan(16588800, built.make_cfg(profile=2, uep=2))      # BASELINE C2
     assert (L.n_sym, L.body_syms, L.out_words) == (143769600, 186900480, 20766726) and list(L.band_blocks) == [798720] * 9
