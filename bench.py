@@ -84,6 +84,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     t3 = ge.load_package()
+    sf = __import__("ternary_image_codec_amd.superframe", fromlist=["x"])
     t3.init(local)
     orc = ol.oracle()
     stream = torch.cuda.current_stream().cuda_stream
@@ -118,13 +119,13 @@ def main():
         assert rc == 0 and n == NPX, (rc, n)
         if ev is not None:
             ev[2].record(stream)
-        t3.frame_record_dev(d_enc.data_ptr(), n_enc, rank * args.steps + i, cfg, d_recs[i % len(d_recs)].data_ptr(), d_scr.data_ptr(), 64, stream)
+        t3.frame_record_dev(d_enc.data_ptr(), n_enc, i * world + rank, cfg, d_recs[i % len(d_recs)].data_ptr(), d_scr.data_ptr(), 64, stream)
 
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
     events = [[t3.Event(), t3.Event(), t3.Event()] for _ in range(args.steps)]
-    gathered = torch.zeros((world * len(d_recs), t3.FRAME_RECORD_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered = None
 
     if world > 1:
         dist.barrier()
@@ -133,7 +134,7 @@ def main():
     for i in range(args.steps):
         step(i, events[i])
     if world > 1 and not args.encode_only:
-        dist.all_gather_into_tensor(gathered, d_recs)      # the one exchange step: super-frame index records
+        gathered = sf.gather_records(d_recs)               # the one exchange step: super-frame index records (RCCL all-gather)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -150,9 +151,10 @@ def main():
     if not args.encode_only:
         back = d_back[: NPX * 6].cpu().numpy().view(ol.PIXEL_DT)
         assert np.array_equal(back, px), "FIXED decode did not recover the frame"
-        recs = (gathered if world > 1 else d_recs).cpu().numpy()
-        index = t3.index_assemble(recs.reshape(-1), 0)
-        assert index[0].n_words == n_enc and index[0].crc32 == orc.crc32(enc) if rank == 0 else True
+        index = sf.assemble_index(gathered if world > 1 else d_recs, 0)
+        assert len(index) == world * args.steps and [r.frame_idx for r in index] == list(range(world * args.steps))
+        mine = index[(args.steps - 1) * world + rank]          # frames are dealt round-robin: frame f lives on rank f % world
+        assert mine.n_words == n_enc and mine.crc32 == orc.crc32(enc), "frame index record does not match the payload"
 
     if rank != 0:
         if world > 1:

@@ -1,0 +1,230 @@
+// ternary_codec_v6.hpp — C++17 drop-in for the Word27 hot path of the reference's
+// old/include/ternary_image_codec_v6_min.hpp (OLD), implemented on MI355X through libt3hip.so (include/t3hip.h).
+//
+// Same names, layouts and call signatures as the reference for everything its callers touch on this path
+// (old/src/main.cpp:15-27, old/include/io_image.hpp:240-246, include/io_image.hpp:286-310, t3v/t3p writers):
+// the types are ABI-identical (Word27 = 9 bytes, PixelYCbCrQuant = 6 bytes), the functions take and fill the same
+// std::vector arguments and return the same bool.  What is different, by design:
+//   * the arithmetic runs in HIP kernels; there is no CPU implementation behind these functions.  If libt3hip.so has no
+//     usable gfx950 device every function returns false and t3::last_status() tells why (T3_E_NODEVICE).
+//   * EncoderConfig / DecoderConfigSeen carry one extra field, `mode` (T3_MODE_COMPAT = byte-exact with the reference,
+//     bugs included; T3_MODE_FIXED = the self-consistent v6c variant that actually round-trips).
+//   * encode_frame / decode_frame fuse pack+encode and decode+unpack into single launches (north-star conveniences).
+// Link with -lt3hip (ternary-image-codec_amd/libt3hip.so).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "t3hip.h"
+
+// ---- symbols and words (OLD:21-31, 666-674) -------------------------------------------------------------
+using UTrit = uint8_t;   // 0..2
+using GF27 = uint8_t;    // 0..26
+static constexpr int TRITS_PER_WORD = 27, SYM_PER_WORD = 9, NUM_BANDS = 9;
+inline GF27 pack3(UTrit a, UTrit b, UTrit c) { return (GF27)(a + 3 * b + 9 * c); }
+inline std::array<UTrit, 3> unpack3(GF27 s) { return {(UTrit)(s % 3), (UTrit)(s / 3 % 3), (UTrit)(s / 9 % 3)}; }
+
+struct Word27 { std::array<GF27, SYM_PER_WORD> sym{}; };
+struct PixelYCbCrQuant { uint16_t Yq = 0; int16_t Cbq = 0, Crq = 0; };
+static_assert(sizeof(Word27) == 9 && sizeof(PixelYCbCrQuant) == 6, "reference ABI");
+
+// ---- profiles, UEP, tiles, scrambler, beacon (OLD:34-114) -------------------------------------------------
+enum class ProfileID : uint8_t { RAW_MODE = 0xFF, P1_RS26_24 = 0, P2_RS26_22 = 1, P3_RS26_20 = 2, P4_RS26_18 = 3, P5_RS26_22_2D = 4 };
+struct RSParams { uint8_t n = 26, k = 22; };
+inline RSParams rs_params_for(ProfileID p) {
+    static const uint8_t ks[5] = {24, 22, 20, 18, 22};
+    const unsigned i = (unsigned)p;
+    return RSParams{26, i < 5 ? ks[i] : (uint8_t)22};
+}
+struct UEPLayout { std::array<uint8_t, NUM_BANDS> band_profile{}; };
+inline void uep_uniform(UEPLayout& u, uint8_t idx = 1) { u.band_profile.fill(idx % 4); }
+inline void uep_luma_priority(UEPLayout& u) { u.band_profile.fill(1); u.band_profile[0] = u.band_profile[3] = u.band_profile[6] = 2; }
+struct Tile2D { uint16_t w = 0, h = 0; };
+struct ScramblerSeed { uint32_t a = 1, b = 1, s0 = 1; };
+struct SparseBeaconCfg { uint32_t words_period = 0; uint8_t band_slot = 0; bool enabled = false; };
+enum class CosetID : uint8_t { C0 = 0, C1 = 1, C2 = 2 };
+
+// ---- subword modes and centring (OLD:117-152) ---------------------------------------------------------------
+enum class SubwordMode : uint8_t { S27 = 27, S24 = 24, S21 = 21, S18 = 18, S15 = 15 };
+inline int payload_len_for(SubwordMode m) { return (int)m; }
+struct StdRes { uint16_t w, h; };
+inline StdRes std_res_for(SubwordMode m) {
+    switch (m) {
+        case SubwordMode::S24: return {3840, 2160};
+        case SubwordMode::S21: return {1920, 1080};
+        case SubwordMode::S18: return {1280, 720};
+        case SubwordMode::S15: return {854, 480};
+        default: return {7680, 4320};
+    }
+}
+struct ActiveWindow { uint32_t x0, y0, w, h; };
+inline ActiveWindow centered_window(SubwordMode m) {
+    const StdRes full = std_res_for(SubwordMode::S27), t = std_res_for(m);
+    return {(uint32_t)((full.w - t.w) / 2), (uint32_t)((full.h - t.h) / 2), t.w, t.h};
+}
+inline bool is_valid_subword(SubwordMode m) { const int v = (int)m; return v == 27 || v == 24 || v == 21 || v == 18 || v == 15; }
+
+// ---- contexts (OLD:862-916) -------------------------------------------------------------------------------------
+struct EncoderConfig {
+    ProfileID profile = ProfileID::P2_RS26_22;
+    UEPLayout uep{};
+    Tile2D tile{};
+    ScramblerSeed seed{1, 1, 1};
+    SparseBeaconCfg beacon{};
+    uint32_t superframe_words = 8192;
+    SubwordMode subword = SubwordMode::S27;
+    bool centered = true;
+    CosetID coset = CosetID::C0;
+    uint8_t mode = T3_MODE_COMPAT;      // build-side: T3_MODE_COMPAT | T3_MODE_FIXED
+};
+struct DecoderConfigSeen {
+    ProfileID profile = ProfileID::P2_RS26_22;
+    UEPLayout uep{};
+    Tile2D tile{};
+    ScramblerSeed seed{1, 1, 1};
+    SparseBeaconCfg beacon{};
+    SubwordMode subword = SubwordMode::S27;
+    bool centered = true;
+    CosetID coset = CosetID::C0;
+    uint8_t mode = T3_MODE_COMPAT;
+};
+// The reference's contexts own GF tables and five RSCodec objects; here those constants live in the library
+// (device-resident, built once in t3hip_init), so a context is just its configuration — and, unlike the
+// reference's (raw pointer into itself, OLD:492), safely copyable.
+struct EncoderContext { EncoderConfig cfg; EncoderContext() { uep_uniform(cfg.uep, 1); } };
+struct DecoderContext { DecoderConfigSeen cfg_last_seen; DecoderContext() { uep_uniform(cfg_last_seen.uep, 1); } };
+
+// ---- header (OLD:155-380) ----------------------------------------------------------------------------------------
+struct SuperframeHeader {
+    uint16_t magic = 0x0A2; uint8_t version = 1;
+    ProfileID profile = ProfileID::P2_RS26_22; UEPLayout uep{}; Tile2D tile{}; ScramblerSeed seed{};
+    uint32_t band_map_hash = 0, frame_seq = 0, reserved = 0, crc3m = 0;
+    SparseBeaconCfg beacon{}; SubwordMode subword = SubwordMode::S27; bool centered = true; CosetID coset = CosetID::C0;
+};
+struct HeaderPack { std::array<GF27, 27> symbols{}; };
+
+namespace t3 {
+inline int& status_slot() { static thread_local int s = T3_OK; return s; }
+inline int last_status() { return status_slot(); }                     // T3_* code of the last call on this thread
+inline bool ok(int rc) { status_slot() = rc; return rc == T3_OK; }
+inline bool ensure_device(int dev = 0) { return t3hip_is_ready() || ok(t3hip_init(dev)); }
+
+template <class Cfg> inline t3_cfg to_pod(const Cfg& c, uint32_t superframe_words) {
+    t3_cfg p; std::memset(&p, 0, sizeof p);
+    p.profile = (uint8_t)c.profile;
+    for (int i = 0; i < 9; ++i) p.band_profile[i] = c.uep.band_profile[i];
+    p.tile_w = c.tile.w; p.tile_h = c.tile.h;
+    p.seed_a = c.seed.a; p.seed_b = c.seed.b; p.seed_s0 = c.seed.s0;
+    p.beacon_words_period = c.beacon.words_period; p.beacon_band_slot = c.beacon.band_slot; p.beacon_enabled = c.beacon.enabled;
+    p.subword = (uint8_t)c.subword; p.centered = c.centered; p.coset = (uint8_t)c.coset; p.mode = c.mode;
+    p.superframe_words = superframe_words;
+    return p;
+}
+inline void from_pod(const t3_cfg& p, DecoderConfigSeen& c) {
+    c.profile = (ProfileID)p.profile;
+    for (int i = 0; i < 9; ++i) c.uep.band_profile[i] = p.band_profile[i];
+    c.tile.w = p.tile_w; c.tile.h = p.tile_h;
+    c.seed.a = p.seed_a; c.seed.b = p.seed_b; c.seed.s0 = p.seed_s0;
+    c.beacon.words_period = p.beacon_words_period; c.beacon.band_slot = p.beacon_band_slot; c.beacon.enabled = p.beacon_enabled != 0;
+    c.subword = (SubwordMode)p.subword; c.centered = p.centered != 0; c.coset = (CosetID)p.coset; c.mode = p.mode;
+}
+}  // namespace t3
+
+struct HeaderCodec {
+    static HeaderPack pack(const SuperframeHeader& h) {
+        EncoderConfig c; c.profile = h.profile; c.uep = h.uep; c.tile = h.tile; c.seed = h.seed; c.beacon = h.beacon;
+        c.subword = h.subword; c.centered = h.centered; c.coset = h.coset;
+        const t3_cfg p = t3::to_pod(c, 0);
+        HeaderPack out; t3hip_header_pack(&p, h.frame_seq, h.band_map_hash, out.symbols.data());
+        return out;
+    }
+    static bool check(const HeaderPack& p) { return t3hip_header_check(p.symbols.data()) == 1; }
+    static SuperframeHeader unpack(const HeaderPack& p) {
+        t3_cfg c; std::memset(&c, 0, sizeof c); uint32_t fs = 0, bh = 0;
+        t3hip_header_unpack(p.symbols.data(), &c, &fs, &bh);
+        DecoderConfigSeen d; t3::from_pod(c, d);
+        SuperframeHeader h; h.magic = (uint16_t)(p.symbols[0] % 27 + 27 * (p.symbols[1] % 27)); h.version = p.symbols[2] % 27;
+        h.profile = d.profile; h.uep = d.uep; h.tile = d.tile; h.seed = d.seed; h.beacon = d.beacon;
+        h.subword = d.subword; h.centered = d.centered; h.coset = d.coset; h.frame_seq = fs; h.band_map_hash = bh;
+        return h;
+    }
+};
+
+// ---- RAW packer (OLD:723-747; `_subword` variants NEWH:113-125 / NEWC:139-155) ------------------------------------
+inline bool encode_raw_pixels_to_words(const std::vector<PixelYCbCrQuant>& px, std::vector<Word27>& out) {
+    out.clear();
+    if (!t3::ensure_device()) return false;
+    out.resize((px.size() + 1) / 2);
+    return t3::ok(t3hip_pack_pixels(px.data(), px.size(), out.data()));
+}
+inline bool decode_raw_words_to_pixels(const std::vector<Word27>& in, std::vector<PixelYCbCrQuant>& out) {
+    out.clear();
+    if (!t3::ensure_device()) return false;
+    out.resize(in.size() * 2);
+    return t3::ok(t3hip_unpack_words(in.data(), in.size(), out.data()));
+}
+inline bool encode_raw_pixels_to_words_subword(const std::vector<PixelYCbCrQuant>& px, SubwordMode sub, std::vector<Word27>& out) {
+    if (!is_valid_subword(sub)) { t3::status_slot() = T3_E_ARG; return false; }
+    return encode_raw_pixels_to_words(px, out);
+}
+inline bool decode_raw_words_to_pixels_subword(const std::vector<Word27>& in, SubwordMode sub, std::vector<PixelYCbCrQuant>& out) {
+    if (!is_valid_subword(sub)) { t3::status_slot() = T3_E_ARG; return false; }
+    return decode_raw_words_to_pixels(in, out);
+}
+
+// ---- profile encode / decode (OLD:995-1169) --------------------------------------------------------------------------
+inline bool encode_profile_from_raw(const std::vector<Word27>& in, std::vector<Word27>& out, EncoderContext& ectx) {
+    out.clear();
+    if (!t3::ensure_device()) return false;
+    const t3_cfg c = t3::to_pod(ectx.cfg, ectx.cfg.superframe_words);
+    const uint64_t cap = t3hip_encoded_words(in.size(), &c);
+    out.resize(cap); uint64_t n = 0;
+    const bool good = t3::ok(t3hip_encode_profile(in.data(), in.size(), &c, out.data(), cap, &n));
+    out.resize(good ? n : 0);
+    return good;
+}
+inline bool decode_profile_to_raw(const std::vector<Word27>& in, std::vector<Word27>& out, DecoderContext& dctx) {
+    out.clear();
+    if (!t3::ensure_device()) return false;
+    t3_cfg c = t3::to_pod(dctx.cfg_last_seen, 0);
+    out.resize(in.size() + 16); uint64_t n = 0;
+    const int rc = t3hip_decode_profile(in.data(), in.size(), &c, out.data(), out.size(), &n);
+    t3::from_pod(c, dctx.cfg_last_seen);                 // the header, once decoded, is remembered even if a block fails (OLD:1006-1017)
+    out.resize(rc == T3_OK ? n : 0);
+    return t3::ok(rc);
+}
+// pixels -> coded words and back in one launch each (= OLD:723 + OLD:1043, OLD:995 + OLD:735)
+inline bool encode_frame(const std::vector<PixelYCbCrQuant>& px, std::vector<Word27>& out, EncoderContext& ectx) {
+    out.clear();
+    if (!t3::ensure_device()) return false;
+    const t3_cfg c = t3::to_pod(ectx.cfg, ectx.cfg.superframe_words);
+    const uint64_t cap = t3hip_encoded_words((px.size() + 1) / 2, &c);
+    out.resize(cap); uint64_t n = 0;
+    const bool good = t3::ok(t3hip_encode_frame(px.data(), px.size(), &c, out.data(), cap, &n));
+    out.resize(good ? n : 0);
+    return good;
+}
+inline bool decode_frame(const std::vector<Word27>& in, std::vector<PixelYCbCrQuant>& px, DecoderContext& dctx) {
+    px.clear();
+    if (!t3::ensure_device()) return false;
+    t3_cfg c = t3::to_pod(dctx.cfg_last_seen, 0);
+    px.resize(2 * (in.size() + 16)); uint64_t n = 0;
+    const int rc = t3hip_decode_frame(in.data(), in.size(), &c, px.data(), px.size(), &n);
+    t3::from_pod(c, dctx.cfg_last_seen);
+    px.resize(rc == T3_OK ? n : 0);
+    return t3::ok(rc);
+}
+
+// ---- self-tests with the reference's inputs (OLD:1172-1230) ------------------------------------------------------------
+// The reference's own versions fail; these run the same inputs through FIXED mode, where they pass.
+inline bool selftest_api_roundtrip() {
+    std::vector<PixelYCbCrQuant> px(64);
+    for (size_t i = 0; i < px.size(); ++i) { px[i].Yq = (uint16_t)(i * 7 % 243); px[i].Cbq = (int16_t)((int)(i * 3 % 81) - 40); px[i].Crq = (int16_t)((int)(i * 5 % 81) - 40); }
+    std::vector<Word27> raw, coded, back;
+    EncoderContext e; e.cfg.profile = ProfileID::P2_RS26_22; e.cfg.mode = T3_MODE_FIXED; uep_luma_priority(e.cfg.uep);
+    DecoderContext d; d.cfg_last_seen.mode = T3_MODE_FIXED;
+    if (!encode_raw_pixels_to_words(px, raw) || !encode_profile_from_raw(raw, coded, e) || !decode_profile_to_raw(coded, back, d)) return false;
+    return back.size() == raw.size() && std::memcmp(back.data(), raw.data(), raw.size() * 9) == 0;
+}

@@ -102,11 +102,13 @@ __global__ __launch_bounds__(256) void dec_emit_kernel(const EmitArgs a) {
         }
         if (!a.to_pixels) { uint8_t* p = (uint8_t*)a.out + 9 * w; for (int s = 0; s < 9; ++s) p[s] = (uint8_t)sy[s]; }
         else {
-            uint16_t* p = (uint16_t*)a.out + 6 * w;                    // unpack_two_pixels OLD:706-722
-            p[0] = (uint16_t)(sy[0] + 27u * (sy[1] % 9u)); p[1] = (uint16_t)(int16_t)((int)(sy[1] / 9u + 3u * sy[2]) - 40);
-            p[2] = (uint16_t)(int16_t)((int)(sy[3] + 27u * (sy[4] % 3u)) - 40);
-            p[3] = (uint16_t)(sy[4] / 3u + 9u * sy[5]); p[4] = (uint16_t)(int16_t)((int)(sy[6] + 27u * (sy[7] % 3u)) - 40);
-            p[5] = (uint16_t)(int16_t)((int)(sy[7] / 3u + 9u * (sy[8] % 9u)) - 40);
+            uint32_t h[6];                                             // unpack_two_pixels OLD:706-722
+            h[0] = sy[0] + 27u * (sy[1] % 9u); h[1] = (uint32_t)((int)(sy[1] / 9u + 3u * sy[2]) - 40) & 0xFFFFu;
+            h[2] = (uint32_t)((int)(sy[3] + 27u * (sy[4] % 3u)) - 40) & 0xFFFFu;
+            h[3] = sy[4] / 3u + 9u * sy[5]; h[4] = (uint32_t)((int)(sy[6] + 27u * (sy[7] % 3u)) - 40) & 0xFFFFu;
+            h[5] = (uint32_t)((int)(sy[7] / 3u + 9u * (sy[8] % 9u)) - 40) & 0xFFFFu;
+            uint32_t* p = (uint32_t*)((uint8_t*)a.out + 12 * w);       // 12-byte records: three aligned dwords per lane
+            p[0] = h[0] | h[1] << 16; p[1] = h[2] | h[3] << 16; p[2] = h[4] | h[5] << 16;
         }
     }
 }
@@ -175,7 +177,19 @@ __global__ __launch_bounds__(256) void crc_chunks_kernel(const CrcArgs a) {
     if (ch < a.n_chunks) {
         const uint64_t beg = (uint64_t)ch * a.chunk_bytes, end = min(beg + a.chunk_bytes, a.n_bytes);
         uint32_t r = 0;
-        for (uint64_t i = beg; i < end; ++i) { const uint32_t v = a.data[i]; sum += v; r = tbl[(r ^ v) & 0xFFu] ^ (r >> 8); }
+        uint64_t i = beg;                                          // chunk starts are 16-B aligned (2304 = 144 * 16)
+        for (; (((uintptr_t)a.data & 15u) == 0) && i + 16 <= end; i += 16) {
+            const uint4 q = *(const uint4*)(a.data + i);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sum += (w[j] & 0xFFu) + ((w[j] >> 8) & 0xFFu) + ((w[j] >> 16) & 0xFFu) + (w[j] >> 24);
+                r ^= w[j];                                         // four table steps on the xor-ed word (little endian)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) r = tbl[r & 0xFFu] ^ (r >> 8);
+            }
+        }
+        for (; i < end; ++i) { const uint32_t v = a.data[i]; sum += v; r = tbl[(r ^ v) & 0xFFu] ^ (r >> 8); }
         atomicXor(a.chunk_crc, crc_shift(zp, r, a.n_bytes - end));   // move it to the end of the stream
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);

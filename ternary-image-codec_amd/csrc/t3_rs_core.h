@@ -36,9 +36,11 @@ struct RsView {
 template <int R>
 T3_HD bool rs_syndromes(const RsView& g, const uint8_t* c, uint8_t* S) {
     bool zero = true;
+#pragma unroll
     for (int j = 0; j < R; ++j) {
         uint8_t acc = 0;
-        for (int i = 0; i < 26; ++i) acc = g.A(acc, g.M(c[i], g.P(((j + 1) * i) % 26)));
+#pragma unroll
+        for (int i = 0; i < 26; ++i) acc = g.A(acc, g.M(c[i], g.exp[((j + 1) * i) % 26]));   // exponent is a compile-time constant
         S[j] = acc;
         zero = zero && acc == 0;
     }
@@ -82,23 +84,26 @@ T3_HD bool rs_correct(const RsView& g, uint8_t* c, const uint8_t* S, bool fixed)
         for (int j = 0; j < ns; ++j) if (j <= q) acc = g.A(acc, g.M(S[q - j], sg[j]));
         Om[q] = acc;
     }
+    // Horner over the trailing zero coefficients of the reference's vector contributes nothing: start at the true degree
+    int deg = ns - 1; while (deg > 0 && sg[deg] == 0) --deg;
     int pos[T + 1], np = 0;
     for (int i = 0; i < 26; ++i) {
-        const uint8_t x = g.P(-i);
-        uint8_t acc = 0;
-        for (int q = ns - 1; q >= 0; --q) acc = g.A(g.M(acc, x), sg[q]);
+        const uint8_t x = g.exp[i == 0 ? 0 : 26 - i];            // alpha^{-i}
+        uint8_t acc = sg[deg];
+        for (int q = deg - 1; q >= 0; --q) acc = g.A(g.M(acc, x), sg[q]);
         if (acc == 0) { if (np < T + 1) pos[np] = i; ++np; }
     }
     if (np > T) return false;
-    if (fixed) { int deg = ns - 1; while (deg > 0 && sg[deg] == 0) --deg; if (np != deg) return false; }
+    if (fixed && np != deg) return false;
     uint8_t dp[NP]; const int ndp = ns > 1 ? ns - 1 : 1;
     for (int i = 0; i < NP; ++i) dp[i] = 0;
     for (int i = 1; i < ns; ++i) { const int im = i % 3; dp[i - 1] = im == 0 ? 0 : (im == 1 ? sg[i] : g.A(sg[i], sg[i])); }
+    int ddeg = ndp - 1; while (ddeg > 0 && dp[ddeg] == 0) --ddeg;
     for (int e = 0; e < np; ++e) {
-        const uint8_t xi = g.P(-pos[e]);
-        uint8_t num = 0, den = 0;
+        const uint8_t xi = g.exp[pos[e] == 0 ? 0 : 26 - pos[e]];
+        uint8_t num = 0, den = dp[ddeg];
         for (int q = R - 1; q >= 0; --q) num = g.A(g.M(num, xi), Om[q]);
-        for (int q = ndp - 1; q >= 0; --q) den = g.A(g.M(den, xi), dp[q]);
+        for (int q = ddeg - 1; q >= 0; --q) den = g.A(g.M(den, xi), dp[q]);
         if (den == 0) return false;
         const uint8_t mag = g.M(g.neg[num], g.inv[den]);
         c[pos[e]] = fixed ? g.S(c[pos[e]], mag) : g.A(c[pos[e]], mag);

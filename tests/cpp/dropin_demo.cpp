@@ -1,0 +1,37 @@
+// tests/cpp/dropin_demo.cpp — the reference's canonical caller sequence (old/src/main.cpp:15-27: quantised pixels ->
+// encode_raw_pixels_to_words -> EncoderContext{P2, tile 64x64, beacon {83,2,true}} -> encode_profile_from_raw ->
+// decode_profile_to_raw) written against include/ternary_codec_v6.hpp, i.e. what a maintainer gets by swapping the include.
+// Prints one JSON line; tests/test_gpu_dropin.py checks it against the oracle.  Host compiler only (g++), links -lt3hip.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ternary_codec_v6.hpp"
+
+static uint64_t fnv(const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } return h; }
+
+int main(int argc, char** argv) {
+    const int w = argc > 1 ? atoi(argv[1]) : 256, h = argc > 2 ? atoi(argv[2]) : 256;
+    std::vector<PixelYCbCrQuant> q((size_t)w * h);
+    uint32_t s = 12345;                                      // SURVEY §8d generator
+    auto draw = [&]() { s = s * 1664525u + 1013904223u; return s >> 8; };
+    for (auto& p : q) { p.Yq = (uint16_t)(draw() % 243); p.Cbq = (int16_t)((int)(draw() % 81) - 40); p.Crq = (int16_t)((int)(draw() % 81) - 40); }
+
+    std::vector<Word27> raw; bool ok_raw = encode_raw_pixels_to_words(q, raw);
+    EncoderContext e; e.cfg.profile = ProfileID::P2_RS26_22; e.cfg.tile = {64, 64}; e.cfg.beacon = {83, 2, true};   // old/src/main.cpp:19
+    std::vector<Word27> prof; bool ok_enc = encode_profile_from_raw(raw, prof, e);
+    DecoderContext d; std::vector<Word27> raw2; bool ok_dec = decode_profile_to_raw(prof, raw2, d);                    // reference: false
+
+    EncoderContext ef = e; ef.cfg.mode = T3_MODE_FIXED;     // the variant that does round-trip
+    std::vector<Word27> proff; bool ok_encf = encode_frame(q, proff, ef);
+    DecoderContext df; df.cfg_last_seen.mode = T3_MODE_FIXED;
+    std::vector<PixelYCbCrQuant> q2; bool ok_decf = decode_frame(proff, q2, df);
+    bool same = ok_decf && q2.size() == q.size() && memcmp(q2.data(), q.data(), q.size() * 6) == 0;
+
+    printf("{\"ok_raw\":%d,\"raw_words\":%zu,\"raw_hash\":\"%016llx\",\"ok_enc\":%d,\"enc_words\":%zu,\"enc_hash\":\"%016llx\",\"ok_dec_compat\":%d,"
+           "\"seen_profile\":%d,\"seen_tile_w\":%d,\"ok_enc_fixed\":%d,\"ok_dec_fixed\":%d,\"roundtrip_equal\":%d,\"selftest_api_roundtrip\":%d,\"status\":%d}\n",
+           ok_raw, raw.size(), (unsigned long long)fnv(raw.data(), raw.size() * 9), ok_enc, prof.size(), (unsigned long long)fnv(prof.data(), prof.size() * 9), ok_dec,
+           (int)d.cfg_last_seen.profile, (int)d.cfg_last_seen.tile.w, ok_encf, ok_decf, same, selftest_api_roundtrip(), t3::last_status());
+    return 0;
+}

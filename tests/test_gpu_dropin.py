@@ -1,0 +1,48 @@
+"""The C++ drop-in header (include/ternary_codec_v6.hpp) driven the way the reference's own CLI drives the reference
+(old/src/main.cpp:15-27), compiled with the host compiler only and linked against libt3hip.so."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_demo(tmp):
+    exe = os.path.join(tmp, "dropin_demo")
+    lib = os.path.join(ROOT, "ternary-image-codec_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "dropin_demo.cpp"),
+                    "-L" + lib, "-lt3hip", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    return exe
+
+
+def test_dropin_header_compiles_and_refuses_without_gpu(t3, tmp_path):
+    """CPU: the header builds with g++ alone; with no device every call returns false with T3_E_NODEVICE (no fallback)."""
+    import torch
+    exe = build_demo(str(tmp_path))
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu test")
+    out = json.loads(subprocess.run([exe, "16", "16"], check=True, capture_output=True, text=True).stdout)
+    assert out["ok_raw"] == 0 and out["ok_enc"] == 0 and out["ok_enc_fixed"] == 0 and out["status"] == -1
+
+
+@pytest.mark.gpu
+def test_dropin_caller_sequence(gpu, orc, tmp_path):
+    exe = build_demo(str(tmp_path))
+    out = json.loads(subprocess.run([exe, "256", "256"], check=True, capture_output=True, text=True).stdout)
+    px = orc.lcg_pixels(256 * 256)
+    raw = orc.pack_pixels(px)
+    cfg = ol.make_cfg(profile=1, uep=1, tile=(64, 64), beacon=(83, 2, 1))
+    rc, enc = orc.encode_profile(raw, cfg)
+    assert out["ok_raw"] == 1 and out["raw_words"] == len(raw) and out["raw_hash"] == ol.fnv_hex(raw)
+    assert out["ok_enc"] == 1 and out["enc_words"] == len(enc) and out["enc_hash"] == ol.fnv_hex(enc)
+    seen = ol.make_cfg()
+    rcd, _ = orc.decode_profile(enc, seen)
+    assert out["ok_dec_compat"] == (1 if rcd == 0 else 0)
+    if rcd == 0 or seen.profile != ol.make_cfg().profile:
+        assert out["seen_profile"] == seen.profile
+    assert out["ok_enc_fixed"] == 1 and out["ok_dec_fixed"] == 1 and out["roundtrip_equal"] == 1 and out["selftest_api_roundtrip"] == 1
