@@ -131,3 +131,21 @@ def test_selftest_inputs_known_answers(orc):
         pat = ((np.arange(k) * 5 + 7) % 27).astype(np.uint8)
         assert list(orc.rs_encode_blocks(k, pat)[0, k:]) == GOLD["rs"][str(k)]["pattern_parity"]
     assert GOLD["selftests"] == [False, False]
+
+
+def test_device_division_tricks_are_exact():
+    """The kernels divide by powers of three with 24-bit multiplies and reduce 16-bit components with a float reciprocal
+    (csrc/t3_kernels.hip: div3/div9/div27/div81, red_y, red_c).  Exhaustive check of those formulas over their domains."""
+    x = np.arange(512, dtype=np.uint64)
+    assert ((x * 171) >> 9 == x // 3).all() and ((x * 228) >> 11 == x // 9).all() and ((x * 152) >> 12 == x // 27).all()
+    x = np.arange(885, dtype=np.uint64)
+    assert ((x * 405) >> 15 == x // 81).all()
+    y = np.arange(65536, dtype=np.uint32)
+    for d in (243, 81):
+        q = ((y.astype(np.float32) + np.float32(0.5)) * (np.float32(1.0) / np.float32(d))).astype(np.uint32)
+        assert (q == y // d).all()
+    c = np.arange(-32768, 32768, dtype=np.int64)
+    v = c + 40
+    want = (v % (1 << 32)) % 81                          # (uint32_t)(Cbq + 40) % 81, as i2tr sees it (OLD:698)
+    xx = np.where(v < 0, v + 32854, v)
+    assert (xx >= 0).all() and (xx < 65536).all() and (xx % 81 == want).all()
