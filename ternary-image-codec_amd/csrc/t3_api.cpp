@@ -2,6 +2,7 @@
 // Host logic only; all arithmetic on the data path happens in t3_kernels.hip / t3_decode.hip.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -98,7 +99,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
                 waves += (nb + 63) / 64; blocks_total += nb; outb += round16(26 * nb + 32);
             }
             if (waves > (uint32_t)kMaxWaves) break;
-            const uint32_t groups = (uint32_t)(9 * Lq / GS) + 3, stage = groups * GB + 1024 + 32;   // +1 KiB: LDS-DMA pieces are whole
+            const uint32_t groups = (uint32_t)(9 * Lq / GS) + 6, stage = groups * GB + 1024 + 32;   // +1 KiB: LDS-DMA pieces are whole
             const uint32_t total = kLdsHdr + round16(lut_bytes) + round16((uint32_t)(9 * Lq)) + 16 + 2 * std::max(round16(stage), outb);
             if (total > budget) break;
             const double util = (double)blocks_total / (64.0 * waves);
@@ -112,7 +113,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     uint32_t off = kLdsHdr + a.lut_bytes;
     a.sym_off = off; off += round16(9 * Lq) + 16;
     a.stage_off = off;
-    a.stage_groups = 9 * Lq / GS + 3;
+    a.stage_groups = 9 * Lq / GS + 6;
     uint32_t outb = 0, nw = 0, n_tiles = 0;
     for (int b = 0; b < 9; ++b) {
         a.band_k[b] = L.band_k[b]; a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b];
@@ -125,6 +126,8 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
         n_tiles = std::max<uint32_t>(n_tiles, (uint32_t)((L.band_blocks[b] + nb - 1) / nb));
     }
     a.n_waves = nw; a.n_tiles = n_tiles;
+    a.p3_private = (nw == 9 && band_mask == 0x1FF) ? 1u : 0u;
+    for (uint32_t w = 0; w < nw && a.p3_private; ++w) if (a.wave_band[w] != w) a.p3_private = 0;
     a.stage_stride = std::max(round16(a.stage_groups * GB + 1024 + 32), outb);
     a.lds_bytes = a.stage_off + 2 * a.stage_stride;
     a.n_sym = (uint32_t)L.n_sym;
@@ -153,7 +156,9 @@ int launch_fn(const void* fn, const EncLaunch& e, hipStream_t s) {
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)e.block, e.a.lds_bytes));
         it = occ_cache.emplace(key, std::max(1, occ)).first;
     }
-    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(e.a.n_tiles, (uint32_t)(g.n_cu * it->second)));
+    static const int occ_cap = getenv("T3HIP_MAX_WG_PER_CU") ? atoi(getenv("T3HIP_MAX_WG_PER_CU")) : 0;   // measurement knob
+    const int per_cu = occ_cap > 0 ? std::min(occ_cap, it->second) : it->second;
+    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(e.a.n_tiles, (uint32_t)(g.n_cu * per_cu)));
 #ifdef T3_STAMPS
     static uint64_t* d_dbg = nullptr; static int calls = 0;
     if (!d_dbg) HIPCHK(hipMalloc((void**)&d_dbg, 8 * 8 * 4096));
@@ -167,10 +172,11 @@ int launch_fn(const void* fn, const EncLaunch& e, hipStream_t s) {
         std::vector<uint64_t> h(8 * grid);
         HIPCHK(hipStreamSynchronize(s));
         HIPCHK(hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double acc[6] = {0, 0, 0, 0, 0, 0};
-        for (uint32_t w = 0; w < grid; ++w) for (int i = 0; i < 6; ++i) acc[i] += (double)h[8 * w + i];
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t w = 0; w < grid; ++w) for (int i = 0; i < 8; ++i) acc[i] += (double)h[8 * w + i];
         fprintf(stderr, "[t3 stamps] grid=%u tiles=%u  mean cycles/WG: stage=%.0f p1=%.0f p2=%.0f p3=%.0f total=%.0f  clock=%.3f GHz\n", grid, e.a.n_tiles,
                 acc[0] / grid, acc[1] / grid, acc[2] / grid, acc[3] / grid, acc[4] / grid, acc[4] / acc[5] * 0.1);
+        fprintf(stderr, "[t3 stamps]   p1 split (wave 0): prefetch issue=%.0f convert=%.0f barrier wait=%.0f\n", acc[6] / grid, acc[7] / grid, acc[1] / grid);
     }
 #endif
     return T3_OK;

@@ -38,6 +38,7 @@ struct EncArgs {
     uint32_t  wave_band[kMaxWaves]; // phase-2 role of each wave: band ...
     uint32_t  wave_blk0[kMaxWaves]; // ... and first tile-local block it covers (one block per lane)
     uint32_t  n_waves;
+    uint32_t  p3_private;           // 1 when wave w alone produces band w (its copy-out needs no workgroup barrier)
     uint32_t  sym_off, stage_off, lds_bytes;   // LDS carve-up: [hdr][LUT][symbols][stage 0][stage 1]
     uint32_t  stage_stride;         // bytes between the two input stage buffers (out staging aliases the current one)
     uint32_t  stage_groups;         // capacity of one input stage buffer, in lane groups

@@ -126,10 +126,10 @@ bool rs_decode_host(int k, uint8_t* c, bool fixed) {
 LutGeom lut_geom(int k) {
     LutGeom g; g.k = k; g.r = 26 - k;
     switch (g.r) {
-        case 2: g.n_dw = 3; g.scr_dw = 2; g.scr_shift = 16; g.slab_bytes = 256 + 128; break;
-        case 4: g.n_dw = 3; g.scr_dw = 3; g.scr_shift = 0;  g.slab_bytes = 512; break;
-        case 6: g.n_dw = 4; g.scr_dw = 3; g.scr_shift = 18; g.slab_bytes = 512; break;
-        default: g.n_dw = 5; g.scr_dw = 5; g.scr_shift = 0; g.slab_bytes = 768; break;
+        case 2: g.n_dw = 3; g.var_dw = 2; g.var_off = 256; g.slab_bytes = 1024; break;
+        case 4: g.n_dw = 3; g.var_dw = 2; g.var_off = 256; g.slab_bytes = 1024; break;
+        case 6: g.n_dw = 4; g.var_dw = 2; g.var_off = 256; g.slab_bytes = 1024; break;
+        default: g.n_dw = 5; g.var_dw = 4; g.var_off = 512; g.slab_bytes = 1280; break;
     }
     g.total_bytes = k * g.slab_bytes;
     return g;
@@ -152,11 +152,14 @@ void build_encode_lut(int k, int mode, std::vector<uint32_t>& image) {
                 if (j < nmain) for (int q = 0; q < 3; ++q) dw[q] |= (uint32_t)tr[q] << (6 * j);
                 else for (int q = 0; q < 3; ++q) { const int f = 3 * (j - 5) + q; dw[3 + f / 5] |= (uint32_t)tr[q] << (6 * (f % 5)); }
             }
-            dw[G.scr_dw] |= ((uint32_t)add13((uint8_t)d, 1) | (uint32_t)add13((uint8_t)d, 2) << 5) << G.scr_shift;
-            slab[2 * d] = dw[0]; slab[2 * d + 1] = dw[1];                       // table A: b64 {dw0,dw1}
-            if (r == 2) slab[64 + d] = dw[2];                                      // table B32
-            else { slab[64 + 2 * d] = dw[2]; slab[64 + 2 * d + 1] = dw[3]; }       // table B: b64 {dw2,dw3}
-            if (r == 8) { slab[128 + 2 * d] = dw[4]; slab[128 + 2 * d + 1] = dw[5]; }  // table C: b64 {dw4,dw5}
+            slab[2 * d] = dw[0]; slab[2 * d + 1] = dw[1];                       // table A: {dw0,dw1}
+            if (r == 8) { slab[64 + 2 * d] = dw[2]; slab[64 + 2 * d + 1] = dw[3]; }  // table B (r=8): {dw2,dw3}
+            for (int s = 0; s < 3; ++s) {                                        // variant tables V_s, s = scrambler state
+                uint32_t* v = slab + G.var_off / 4 + 64 * s + 2 * d;
+                const uint32_t img = (uint32_t)add13((uint8_t)d, s) << 24;       // scrambled image of d in the top byte
+                if (r == 6) { v[0] = dw[2]; v[1] = dw[3] | img; }
+                else { v[0] = dw[G.var_dw] | img; v[1] = 0; }
+            }
         }
     }
 }

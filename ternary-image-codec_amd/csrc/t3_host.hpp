@@ -36,18 +36,18 @@ bool rs_decode_host(int k, uint8_t* c26, bool fixed);   // decode_block OLD:546-
 // dword layout ("main" = first min(r,5) parities, plane-major; "extra" = the remaining ones, 3 fields each):
 //   dw0/dw1/dw2 : trit 0/1/2 of parity j at bits [6j, 6j+6), j < min(r,5)
 //   dw3..       : extra parity e = j-5: trit c at field 3e+c (5 fields per dword)
-//   scr         : T1[d] | T2[d] << 5, T_s[d] = d + 13 s trit-wise  (scramble_symbol OLD:81-87)
+//   img         : T_s[d] = d + 13 s trit-wise (scramble_symbol OLD:81-87), in the top byte of the variant table entry
 struct LutGeom {
     int k, r;
     int n_dw;          // accumulator dwords: r=2,4 -> 3; r=6 -> 4; r=8 -> 5
-    int scr_dw;        // dword that carries the scramble images in its top bits
-    int scr_shift;     // bit position of T1 inside that dword (T2 at +5)
-    int slab_bytes;    // LDS bytes per data position (27 entries per table, tables 256-B aligned for b64)
+    int var_dw;        // accumulator dword that lives in the three per-scrambler-state variant tables
+    int var_off;       // byte offset of variant table 0 inside the slab (variants are 256 B apart)
+    int slab_bytes;    // LDS bytes per data position (27 entries x 8 B per table, tables 256-B aligned: conflict-free b64)
     int total_bytes;   // k * slab_bytes
 };
 LutGeom lut_geom(int k);
-// Image: for position p: [tableA: 27 x {dw0,dw1}] pad to 256 B, [tableB: 27 x {dw2,dw3}] pad to 256 B
-// (r>=6) or [tableB32: 27 x dw2] pad to 128 B (r<6), [tableC32: 27 x dw4] pad to 128 B (r=8).
+// Image per position p (entries are 8 B so that the LDS index is the pre-scaled symbol 8*d):
+//   [A: 27 x {dw0,dw1}] [B (r=8 only): 27 x {dw2,dw3}] [V_0][V_1][V_2], V_s: 27 x {dw2, dw3|img<<24} (r=6) or {dwv|img<<24, 0}.
 void build_encode_lut(int k, int mode, std::vector<uint32_t>& image);
 
 // ---- scrambler (OLD:77-94) ------------------------------------------------------------------------

@@ -8,6 +8,7 @@
 //      rs_encode_blocks_kernel  block-level RSCodec::encode_block        (OLD:517-535)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "t3_device.h"
 #include "t3_rs_core.h"
@@ -132,16 +133,16 @@ __device__ __forceinline__ uint32_t mod3x5(uint32_t x) {
 #ifndef T3_ENC_CHUNK
 #define T3_ENC_CHUNK 5      // data symbols whose LUT reads may be in flight together
 #endif
-template <int R> struct LutGeo;
-template <> struct LutGeo<2> { static constexpr int SLAB = 384, SCR_SHIFT = 16; };
-template <> struct LutGeo<4> { static constexpr int SLAB = 512, SCR_SHIFT = 0; };
-template <> struct LutGeo<6> { static constexpr int SLAB = 512, SCR_SHIFT = 18; };
-template <> struct LutGeo<8> { static constexpr int SLAB = 768, SCR_SHIFT = 0; };
+template <int R> struct LutGeo;     // must match lut_geom() in t3_host.cpp
+template <> struct LutGeo<2> { static constexpr uint32_t SLAB = 1024, VOFF = 256; };
+template <> struct LutGeo<4> { static constexpr uint32_t SLAB = 1024, VOFF = 256; };
+template <> struct LutGeo<6> { static constexpr uint32_t SLAB = 1024, VOFF = 256; };
+template <> struct LutGeo<8> { static constexpr uint32_t SLAB = 1280, VOFF = 512; };
 
-struct Blk26 { uint32_t w[7]; };
+struct Blk26 { uint32_t w[7]; };   // 26 output bytes, little-endian packed (w[6] holds 2)
 struct BandRow { uint32_t k, nbt, blocks, lut_off, out_off, boff6; uint64_t body_off; };   // 32 B, LDS header row b
 __device__ __forceinline__ BandRow band_row(uint32_t b) { return *(const BandRow*)(lds + 32u * b); }
-__device__ __forceinline__ uint32_t wave_role(uint32_t wave, uint32_t f) { return *(const uint32_t*)(lds + 288u + 8u * wave + 4u * f); }   // 26 output bytes, little-endian packed (w[6] holds 2)
+__device__ __forceinline__ uint32_t wave_role(uint32_t wave, uint32_t f) { return *(const uint32_t*)(lds + 288u + 8u * wave + 4u * f); }
 
 __device__ __forceinline__ uint32_t add13(uint32_t d, uint32_t s) {   // d + (s,s,s) trit-wise (scramble_symbol OLD:81-87)
     const uint32_t q1 = div3(d), q2 = div9(d);
@@ -150,21 +151,25 @@ __device__ __forceinline__ uint32_t add13(uint32_t d, uint32_t s) {   // d + (s,
     return t0 + 3u * t1 + 9u * t2;
 }
 
-// One RS block: K data symbols read at stride 9 from the stream-ordered LDS symbol buffer, parity through the
-// per-position LUT (two or three conflict-free ds_read_b64 per symbol), scrambling folded into the same reads.
-//   sym_addr : LDS byte address of the block's first data symbol
-//   lut      : LDS byte address of the band's LUT
+// One RS block.  The stream-ordered LDS symbol buffer holds symbols PRE-SCALED by 8 (= the byte offset of the symbol's
+// 8-byte LUT entry), so a data symbol costs: one ds_read_u8, then per table one ds_read_b64/b32 whose address is that
+// byte plus an immediate — no address arithmetic for the fixed tables.  Parity contributions arrive as 6-bit SWAR trit
+// fields (5 per dword; k*2+2 <= 50 < 64, no carries) and are folded mod 3 once per block.  The table that carries the
+// last accumulator dword exists in three variants, one per scrambler state, and holds the scrambled image of the symbol
+// in its top byte: choosing the variant (one add of a per-lane class base) scrambles, one v_perm_b32 places the byte.
+//   sym_addr : LDS byte address of the block's first data symbol;  lut: LDS byte address of the band's LUT
 //   c0       : scrambler cycle phase of the block's first body symbol ((i0 - 2) mod 6)
 //   first    : block starts at body symbol 0 (the two pre-period states apply)
-template <int R>
-__device__ __forceinline__ Blk26 encode_block(uint32_t sym_addr, uint32_t lut, uint32_t c0, bool first, const EncArgs& a) {
-    constexpr int K = 26 - R;
+template <int R, bool FIXED_LUT>
+__device__ __forceinline__ Blk26 encode_block(uint32_t sym_addr, uint32_t lut_rt, uint32_t c0, bool first, const EncArgs& a) {
+    constexpr uint32_t K = 26 - R;
     using G = LutGeo<R>;
-    uint32_t st[6], sh[6];                          // scrambler state per residue class of the position (6-periodic)
+    const uint32_t lut = FIXED_LUT ? (uint32_t)kLdsHdr : lut_rt;       // single-k launches: LUT sits right behind the header
+    uint32_t st[6], vb[6];                          // scrambler state per residue class of the position (6-periodic)
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         st[q] = (a.cyc24 >> (2u * (c0 + q))) & 3u;
-        sh[q] = (uint32_t)G::SCR_SHIFT + 5u * (st[q] >> 1);   // T1 at SCR_SHIFT, T2 at SCR_SHIFT+5; unused when st==0
+        vb[q] = (FIXED_LUT ? 0u : lut) + (st[q] << 8);                   // variant tables are 256 B apart
     }
     uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0;
     Blk26 o;
@@ -172,29 +177,29 @@ __device__ __forceinline__ Blk26 encode_block(uint32_t sym_addr, uint32_t lut, u
     for (int i = 0; i < 7; ++i) o.w[i] = 0;
     uint32_t d0 = 0, d1 = 0;
 #pragma unroll
-    for (int p = 0; p < K; ++p) {
-        const uint32_t d = lds[sym_addr + 9 * p];
-        if (p == 0) d0 = d;
-        if (p == 1) d1 = d;
-        const uint32_t e = lut + (uint32_t)(p * G::SLAB) + d * 8u;
-        const uint2 A = *(const uint2*)(lds + e);
+    for (uint32_t p = 0; p < K; ++p) {
+        const uint32_t d8 = lds[sym_addr + 9u * p];
+        if (p == 0) d0 = d8;
+        if (p == 1) d1 = d8;
+        const uint32_t fa = FIXED_LUT ? d8 : d8 + lut;                   // fixed tables: byte offset + immediate
+        const uint2 A = *(const uint2*)(lds + fa + (FIXED_LUT ? lut : 0u) + p * G::SLAB);
         acc0 += A.x; acc1 += A.y;
-        uint32_t scr;
-        if constexpr (R == 2) {
-            const uint32_t B = *(const uint32_t*)(lds + lut + (uint32_t)(p * G::SLAB) + 256u + d * 4u);
-            acc2 += B; scr = B;
+        if constexpr (R == 8) { const uint2 B = *(const uint2*)(lds + fa + (FIXED_LUT ? lut : 0u) + p * G::SLAB + 256u); acc2 += B.x; acc3 += B.y; }
+        const uint32_t va = d8 + vb[p % 6];
+        uint32_t img;
+        if constexpr (R == 6) {
+            const uint2 V = *(const uint2*)(lds + va + (FIXED_LUT ? lut : 0u) + p * G::SLAB + G::VOFF);
+            acc2 += V.x; acc3 += V.y; img = V.y;
         } else {
-            const uint2 B = *(const uint2*)(lds + e + 256u);
-            acc2 += B.x; scr = B.y;
-            if constexpr (R >= 6) acc3 += B.y;
-            if constexpr (R == 8) { const uint2 C = *(const uint2*)(lds + e + 512u); acc4 += C.x; scr = C.y; }
+            const uint32_t V = *(const uint32_t*)(lds + va + (FIXED_LUT ? lut : 0u) + p * G::SLAB + G::VOFF);
+            if constexpr (R == 8) acc4 += V; else acc2 += V;
+            img = V;
         }
-        const uint32_t v = (scr >> sh[p % 6]) & 31u;
-        const uint32_t outp = st[p % 6] == 0 ? d : v;
-        o.w[p >> 2] |= outp << (8 * (p & 3));
+        // result byte (p&3) <- top byte of img, other bytes kept
+        constexpr uint32_t sel[4] = {0x03020107u, 0x03020700u, 0x03070100u, 0x07020100u};
+        o.w[p >> 2] = __builtin_amdgcn_perm(img, o.w[p >> 2], sel[p & 3]);
         if (p % T3_ENC_CHUNK == T3_ENC_CHUNK - 1) {
-            // bound the LUT reads in flight: without this the compiler issues all K*2 reads first and sinks the adds,
-            // which costs ~4 VGPRs per symbol and spills
+            // bound the LUT reads in flight: without this the compiler issues all reads first and sinks the adds (spills)
             asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "+v"(acc4), "+v"(o.w[p >> 2]));
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -224,7 +229,7 @@ __device__ __forceinline__ Blk26 encode_block(uint32_t sym_addr, uint32_t lut, u
 #pragma unroll
     for (int j = 0; j < R; ++j) { const int p = K + j; o.w[p >> 2] |= par[j] << (8 * (p & 3)); }
     if (first)   // body symbols 0 and 1 see the pre-period states (exact whatever the seed; OLD:81-87)
-        o.w[0] = (o.w[0] & 0xFFFF0000u) | add13(d0, a.pre0) | (add13(d1, a.pre1) << 8);
+        o.w[0] = (o.w[0] & 0xFFFF0000u) | add13(d0 >> 3, a.pre0) | (add13(d1 >> 3, a.pre1) << 8);
     return o;
 }
 
@@ -247,7 +252,7 @@ __device__ __forceinline__ uint32_t il_row_end(uint32_t u, const EncArgs& a) {  
     return base + r * a.il_w + min(a.il_w, take - r * a.il_w);
 }
 
-template <int R>
+template <int R, bool FIXED_LUT>
 __device__ __forceinline__ void phase2_band(const EncArgs& a, uint32_t stage, uint32_t tile, uint32_t b, uint32_t m, uint32_t nbt, uint32_t lane) {
     constexpr uint32_t K = 26 - R;
     const uint32_t mg = tile * nbt + m;
@@ -258,7 +263,7 @@ __device__ __forceinline__ void phase2_band(const EncArgs& a, uint32_t stage, ui
     for (int i = 0; i < 7; ++i) o.w[i] = 0;
     if (valid) {
         const uint32_t c0 = (r.boff6 + 2u * (mg % 3u)) % 6u;                         // 26 == 2 (mod 6)
-        o = encode_block<R>(a.sym_off + b + 9u * K * m, r.lut_off, c0, r.body_off == 0 && mg == 0, a);
+        o = encode_block<R, FIXED_LUT>(a.sym_off + b + 9u * K * m, r.lut_off, c0, r.body_off == 0 && mg == 0, a);
     }
     // The staging image is placed so that LDS address == global address (mod 16): the copy-out is then aligned on both
     // sides.  Block starts are only 2-byte aligned, so every lane stores the 7 aligned dwords that cover its 26 bytes and
@@ -361,9 +366,23 @@ __device__ __forceinline__ void convert_groups(const EncArgs& a, uint32_t stage,
 #pragma unroll
                 for (uint32_t i = 0; i < QS; ++i) {
                     const uint32_t n = q * QS + i;
-                    acc |= sq[i] << (8u * (n % EM));
+                    acc |= sq[i] << (3u + 8u * (n % EM));                      // stored pre-scaled by 8 (LUT entry offset)
                     if (n % EM == EM - 1u) {
                         if constexpr (EM == 2u) *(uint16_t*)(lds + dst + (n - 1u)) = (uint16_t)acc; else *(uint32_t*)(lds + dst + (n - 3u)) = acc;
+                        acc = 0;
+                    }
+                }
+            } else if (!IL && live) {
+                // group straddles a tile edge (tile edges are multiples of 4, group starts are even): same wide stores, predicated
+#pragma unroll
+                for (uint32_t i = 0; i < QS; ++i) {
+                    const uint32_t n = q * QS + i;
+                    acc |= sq[i] << (3u + 8u * (n % EM));
+                    if (n % EM == EM - 1u) {
+                        const uint32_t u = u0 + n - (EM - 1u);
+                        if (u >= S0 && u + EM <= S0 + TS) {
+                            if constexpr (EM == 2u) *(uint16_t*)(lds + dst + (n - 1u)) = (uint16_t)acc; else *(uint32_t*)(lds + dst + (n - 3u)) = acc;
+                        }
                         acc = 0;
                     }
                 }
@@ -372,11 +391,91 @@ __device__ __forceinline__ void convert_groups(const EncArgs& a, uint32_t stage,
                 for (uint32_t i = 0; i < QS; ++i) {
                     uint32_t u = u0 + q * QS + i;
                     if constexpr (IL) { if (u >= a.n_sym) continue; u = il_perm(u, a); }
-                    if (u >= S0 && u < S0 + TS) lds[a.sym_off + (u - S0)] = (uint8_t)sq[i];
+                    if (u >= S0 && u < S0 + TS) lds[a.sym_off + (u - S0)] = (uint8_t)(sq[i] << 3);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Phase 1 for pixels, packed: one lane converts TWO pixel triples at once with 16-bit packed VALU ops (v_pk_*): component
+// i of triple A sits in the low half of a register, of triple B = A+2 in the high half (ds_read_u16 + ds_read_u16_d16_hi),
+// every product stays below 2^16.  Both triples of a lane have the same parity, and a wave handles one parity only, so the
+// byte pairing of the 13 output symbols (offset 13t is odd for odd t) is wave-uniform: 6 b16 stores + 1 b8 store per triple.
+// ---------------------------------------------------------------------------------------------------------
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 pk_d3(u16x2 x)  { return (x * (uint16_t)171) >> (uint16_t)9; }    // x < 512 (products < 2^16 for x <= 383)
+__device__ __forceinline__ u16x2 pk_d9(u16x2 x)  { return (x * (uint16_t)228) >> (uint16_t)11; }   // x <= 287
+__device__ __forceinline__ u16x2 pk_d27(u16x2 x) { return (x * (uint16_t)152) >> (uint16_t)12; }   // x <= 431
+__device__ __forceinline__ uint32_t pk_bits(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+// 9 reduced components (Y < 243, C < 81) of a triple pair -> 13 symbol pairs, each already multiplied by 8
+__device__ __forceinline__ void px3x2_to_sym13x8(const u16x2* c, u16x2* s) {
+    const u16x2 Y0 = c[0], B0 = c[1], R0 = c[2], Y1 = c[3], B1 = c[4], R1 = c[5], Y2 = c[6], B2 = c[7], R2 = c[8];
+    const uint16_t k8 = 8, k24 = 24, k72 = 72, k216 = 216;
+    u16x2 q, t;
+    q = pk_d27(Y0); s[0] = Y0 * k8 - q * k216;            t = pk_d3(B0);  s[1] = q * k8 + (B0 - t * (uint16_t)3) * k72;  s[2] = t * k8;
+    q = pk_d27(R0); s[3] = R0 * k8 - q * k216;            t = pk_d9(Y1);  s[4] = q * k8 + (Y1 - t * (uint16_t)9) * k24;  s[5] = t * k8;
+    q = pk_d27(B1); s[6] = B1 * k8 - q * k216;            t = pk_d9(R1);  s[7] = q * k8 + (R1 - t * (uint16_t)9) * k24;
+    const u16x2 y3 = pk_d3(Y2), y9 = pk_d9(Y2), y81 = pk_d9(y9);                                  // Y2/3, Y2/9, Y2/81
+    s[8] = t * k8 + (Y2 - y3 * (uint16_t)3) * k72;
+    s[9] = y3 * k8 - y81 * k216;                                                                   // (Y2/3) % 27 = Y2/3 - 27 (Y2/81)
+    t = pk_d9(B2);  s[10] = y81 * k8 + (B2 - t * (uint16_t)9) * k24;
+    q = pk_d3(R2);  s[11] = t * k8 + (R2 - q * (uint16_t)3) * k72;  s[12] = q * k8;
+}
+
+// Convert the pixel triples that cover stream symbols [S0, S0+TS) from the stage buffer (image byte x = input byte b0 + x).
+__device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, uint32_t stage, uint64_t b0, uint32_t S0, uint32_t TS,
+                                                      uint32_t lane, uint32_t wave, uint32_t nwv) {
+    const uint32_t t_base = (S0 / 13u) & ~3u, t_end = (S0 + TS + 12u) / 13u;     // triples [t_base, t_end) touch the tile
+    const uint32_t wpp = nwv >> 1;                                                // waves per parity
+    if (wave >= 2u * wpp) return;
+    const uint32_t par = wave >= wpp ? 1u : 0u, wv = wave - par * wpp;
+    for (uint32_t e0 = wv * 64u; t_base + 4u * e0 + par < t_end; e0 += wpp * 64u) {
+        const uint32_t tA = t_base + 4u * (e0 + lane) + par, tB = tA + 2u;
+        const bool liveA = tA < t_end, liveB = tB < t_end;
+        const uint32_t src = stage + (uint32_t)((uint64_t)(liveA ? tA : t_base) * 18u - b0);
+        const uint32_t srcB = liveB ? src + 36u : src;
+        u16x2 h[9], c[9];
+        u16x2 over = {0, 0};
+#pragma unroll
+        for (uint32_t i = 0; i < 9; ++i) {
+            h[i] = u16x2{*(const uint16_t*)(lds + src + 2u * i), *(const uint16_t*)(lds + srcB + 2u * i)};
+            c[i] = (i % 3 == 0) ? h[i] : h[i] + (uint16_t)40;
+            over |= __builtin_elementwise_sub_sat(c[i], (u16x2)((uint16_t)((i % 3 == 0) ? 242 : 80)));
+        }
+        if (__builtin_amdgcn_ballot_w64(pk_bits(over) != 0u) != 0) {             // out-of-range quantised values: exact general reduction
+#pragma unroll
+            for (uint32_t i = 0; i < 9; ++i) {
+                const uint32_t lo = h[i].x, hi = h[i].y;
+                c[i] = (i % 3 == 0) ? u16x2{(uint16_t)red_y(lo), (uint16_t)red_y(hi)} : u16x2{(uint16_t)red_c(lo), (uint16_t)red_c(hi)};
+            }
+        }
+        u16x2 s[13];
+        px3x2_to_sym13x8(c, s);
+        // byte pairing: even triple -> shorts (s0,s1)..(s10,s11) + byte s12; odd triple -> byte s0 + shorts (s1,s2)..(s11,s12).
+        // 13 t + par is even and tile edges are multiples of 4, so a short never straddles a tile edge.
+        const uint32_t uA = 13u * tA, uB = uA + 26u;
+        const uint32_t dA = a.sym_off + (uA - S0), dB = dA + 26u;
+        const bool fullA = uA >= S0 && uA + 13u <= S0 + TS, fullB = uB >= S0 && uB + 13u <= S0 + TS;
+        const bool edge = __builtin_amdgcn_ballot_w64((liveA && !fullA) || (liveB && !fullB)) != 0;   // only the tile's first/last waves
+        auto emit = [&](auto parc) {
+            constexpr uint32_t P = decltype(parc)::value;
+#pragma unroll
+            for (uint32_t j = 0; j < 6; ++j) {
+                const uint32_t pr = pk_bits(s[2 * j + P]) | (pk_bits(s[2 * j + 1 + P]) << 8);     // low half: A's short, high half: B's
+                const uint32_t ia = P + 2u * j;
+                if (liveA && (!edge || (uA + ia >= S0 && uA + ia + 2u <= S0 + TS))) *(uint16_t*)(lds + dA + ia) = (uint16_t)pr;
+                if (liveB && (!edge || (uB + ia >= S0 && uB + ia + 2u <= S0 + TS))) *(uint16_t*)(lds + dB + ia) = (uint16_t)(pr >> 16);
+            }
+            constexpr uint32_t is = P ? 0u : 12u;
+            const uint32_t single = pk_bits(s[is]);
+            if (liveA && (!edge || (uA + is >= S0 && uA + is < S0 + TS))) lds[dA + is] = (uint8_t)single;
+            if (liveB && (!edge || (uB + is >= S0 && uB + is < S0 + TS))) lds[dB + is] = (uint8_t)(single >> 16);
+        };
+        if (par) emit(std::integral_constant<uint32_t, 1>{}); else emit(std::integral_constant<uint32_t, 0>{});
     }
 }
 
@@ -385,13 +484,28 @@ __device__ __forceinline__ void convert_groups(const EncArgs& a, uint32_t stage,
 __device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // ... and the one at the top of a tile, which also drains vmcnt: the prefetched input has landed for every wave
 __device__ __forceinline__ void barrier_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Top-of-tile barrier: vmcnt completes in order and the LDS-DMA prefetch of this tile was issued BEFORE the previous tile's
+// `younger` global stores, so waiting until at most `younger` operations are outstanding is exactly "the input has landed"
+// without also waiting for those stores to be acknowledged.
+__device__ __forceinline__ void barrier_input(uint32_t younger) {
+#ifdef T3_NO_COUNTED_VMCNT
+    younger = 0;
+#endif
+    switch (younger) {
+        case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        default: barrier_all(); break;
+    }
+}
 
 // RSEL = 26-k when every band of the launch shares one k (the common case: no dead code paths, fewer registers,
 // 640-thread bound so that two workgroups share a CU); RSEL = 0 handles mixed k with a wave-uniform switch.
 template <int FE, bool IL, int RSEL>
 __device__ __forceinline__ void encode_body(const EncArgs& a) {
     constexpr uint32_t GS = FE == FE_PIXELS ? kGroupSyms : kGroupSymsW;      // symbols per lane group
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwv = nthr >> 6;
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
     const uint32_t TS = 9u * a.Lq;
 
     // per-band geometry and wave roles -> LDS header (kernel arguments must not be indexed dynamically: that would
@@ -418,28 +532,40 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     }
 
 #ifdef T3_STAMPS   // diagnostic build: per-phase cycle sums of wave 0 (never in the product build)
-    uint64_t st_acc[4] = {0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime(), st_t0 = st_prev, st_rt0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime(), st_t0 = st_prev, st_rt0 = __builtin_amdgcn_s_memrealtime();
 #define T3_STAMP(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
 #else
 #define T3_STAMP(i) do { } while (0)
 #endif
 
-    uint32_t it = 0;
+    // first lane group whose input a tile starting at stream symbol S needs (pixels: the packed converter starts at a
+    // multiple of 4 triples = 2 groups)
+    auto first_group = [](uint32_t S) -> uint32_t { return FE == FE_PIXELS ? ((S / 13u) & ~3u) / 2u : S / GS; };
+    uint32_t it = 0, n_st = 0;                                               // n_st: global stores issued since the last prefetch
     if constexpr (!IL) {                                                     // prologue: first tile's input
-        if (blockIdx.x < a.n_tiles) stage_input<FE>(a, a.stage_off, (blockIdx.x * TS) / GS, (blockIdx.x * TS + TS + GS - 1u) / GS, lane, wave, nwv);
+        if (blockIdx.x < a.n_tiles) stage_input<FE>(a, a.stage_off, first_group(blockIdx.x * TS), (blockIdx.x * TS + TS + GS - 1u) / GS, lane, wave, nwv);
     }
     for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x, ++it) {
         const uint32_t S0 = tile * TS;
         const uint32_t stage = a.stage_off + (IL ? 0u : (it & 1u) * a.stage_stride);
         // ---------------- phase 1: input -> stream-ordered symbols in LDS ----------------
         if constexpr (!IL) {
-            barrier_all();                                                    // this tile's input has landed; the other buffer is free
+            barrier_input(n_st);                                              // this tile's input has landed; the other buffer is free
             T3_STAMP(0);
             const uint32_t nxt = tile + gridDim.x;
+#ifndef T3_PREFETCH_AFTER_P1
             if (nxt < a.n_tiles)
-                stage_input<FE>(a, a.stage_off + ((it & 1u) ^ 1u) * a.stage_stride, (nxt * TS) / GS, (nxt * TS + TS + GS - 1u) / GS, lane, wave, nwv);
+                stage_input<FE>(a, a.stage_off + ((it & 1u) ^ 1u) * a.stage_stride, first_group(nxt * TS), (nxt * TS + TS + GS - 1u) / GS, lane, wave, nwv);
+#endif
+            T3_STAMP(4);                                                      // (diagnostic) prefetch issue
 #ifndef T3_ABL_NO_P1
-            convert_groups<FE, false>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, tid, nthr);
+            if constexpr (FE == FE_PIXELS) convert_pixels_packed(a, stage, ((uint64_t)first_group(S0) * kGroupBytes) & ~15ull, S0, TS, lane, wave, nwv);
+            else convert_groups<FE, false>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, tid, nthr);
+#endif
+            T3_STAMP(5);                                                      // (diagnostic) this wave's conversion
+#ifdef T3_PREFETCH_AFTER_P1
+            if (nxt < a.n_tiles)
+                stage_input<FE>(a, a.stage_off + ((it & 1u) ^ 1u) * a.stage_stride, first_group(nxt * TS), (nxt * TS + TS + GS - 1u) / GS, lane, wave, nwv);
 #endif
             barrier_lds();
             T3_STAMP(1);
@@ -466,20 +592,23 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 #ifndef T3_ABL_NO_P2
         if (wave < a.n_waves) {
             const uint32_t b = wave_role(wave, 0), m = wave_role(wave, 1) + lane, nbt = band_row(b).nbt;
-            if constexpr (RSEL != 0) phase2_band<RSEL>(a, stage, tile, b, m, nbt, lane);
+            if constexpr (RSEL != 0) phase2_band<RSEL, true>(a, stage, tile, b, m, nbt, lane);
             else switch (band_row(b).k) {
-                case 24: phase2_band<2>(a, stage, tile, b, m, nbt, lane); break;
-                case 22: phase2_band<4>(a, stage, tile, b, m, nbt, lane); break;
-                case 20: phase2_band<6>(a, stage, tile, b, m, nbt, lane); break;
-                default: phase2_band<8>(a, stage, tile, b, m, nbt, lane); break;
+                case 24: phase2_band<2, false>(a, stage, tile, b, m, nbt, lane); break;
+                case 22: phase2_band<4, false>(a, stage, tile, b, m, nbt, lane); break;
+                case 20: phase2_band<6, false>(a, stage, tile, b, m, nbt, lane); break;
+                default: phase2_band<8, false>(a, stage, tile, b, m, nbt, lane); break;
             }
         }
 #endif
-        barrier_lds();
+        // When every band is produced by exactly one wave (wave w <-> band w), the run a wave copies out in phase 3 is the
+        // run it has just written itself: LDS operations of one wave complete in order, so no workgroup barrier is needed.
+        if (a.p3_private) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else barrier_lds();
         T3_STAMP(2);
 
         // ---------------- phase 3: coalesced copy-out, one band run per wave ----------------
 #ifndef T3_ABL_NO_P3
+        n_st = 0;
         for (uint32_t b = wave; b < 9; b += nwv) {
             const BandRow r = band_row(b);
             const uint32_t nbt = r.nbt;
@@ -490,13 +619,18 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             uint8_t* g = a.body_out + r.body_off + 26ull * first_blk;
             const uint32_t shift = (uint32_t)(uintptr_t)g & 15u;
             const uint32_t src = stage + r.out_off + shift;
-            const uint32_t head = min(Rb, (16u - shift) & 15u);
-            if (2u * lane < head) *(uint16_t*)(g + 2u * lane) = *(const uint16_t*)(lds + src + 2u * lane);
-            const uint32_t nmain = (Rb - head) >> 4;
-            for (uint32_t i = lane; i < nmain; i += 64u)
-                *(uint4*)(g + head + 16u * i) = *(const uint4*)(lds + src + head + 16u * i);
+            // wave-uniform counts in SGPRs: the stores below sit behind scalar branches, so n_st is exactly the number of
+            // store instructions this wave issues after its LDS-DMA prefetch (the top-of-tile wait is vmcnt(n_st))
+            const uint32_t head = __builtin_amdgcn_readfirstlane(min(Rb, (16u - shift) & 15u));
+            const uint32_t nmain = __builtin_amdgcn_readfirstlane((Rb - head) >> 4);
+            if (head) { if (2u * lane < head) *(uint16_t*)(g + 2u * lane) = *(const uint16_t*)(lds + src + 2u * lane); ++n_st; }
+            for (uint32_t i0 = 0; i0 < nmain; i0 += 64u) {
+                const uint32_t i = i0 + lane;
+                if (i < nmain) *(uint4*)(g + head + 16u * i) = *(const uint4*)(lds + src + head + 16u * i);
+                ++n_st;
+            }
             const uint32_t done = head + 16u * nmain, tail = Rb - done;
-            if (2u * lane < tail) *(uint16_t*)(g + done + 2u * lane) = *(const uint16_t*)(lds + src + done + 2u * lane);
+            if (tail) { if (2u * lane < tail) *(uint16_t*)(g + done + 2u * lane) = *(const uint16_t*)(lds + src + done + 2u * lane); ++n_st; }
         }
 #endif
         T3_STAMP(3);
@@ -505,7 +639,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     if (tid == 0 && a.dbg) {
         uint64_t* d = a.dbg + 8ull * blockIdx.x;
         d[0] = st_acc[0]; d[1] = st_acc[1]; d[2] = st_acc[2]; d[3] = st_acc[3];
-        d[4] = __builtin_amdgcn_s_memtime() - st_t0; d[5] = __builtin_amdgcn_s_memrealtime() - st_rt0;
+        d[4] = __builtin_amdgcn_s_memtime() - st_t0; d[5] = __builtin_amdgcn_s_memrealtime() - st_rt0; d[6] = st_acc[4]; d[7] = st_acc[5];
     }
 #endif
 }
