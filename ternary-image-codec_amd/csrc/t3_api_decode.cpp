@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
+#include <map>
 #include <vector>
 
 #include "../../include/t3hip.h"
@@ -21,6 +24,53 @@ using namespace t3;
 namespace {
 uint32_t* d_zpow = nullptr;     // CRC "append 2^j zero bytes" operators
 uint32_t* d_crc_acc = nullptr;  // [0] xor accumulator, [1] symbol sum
+FxTables* d_fxtab = nullptr;    // field tables of the fused FIXED decoder
+uint32_t* d_synd_lut[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t synd_lut_bytes[4] = {0, 0, 0, 0};   // per k index
+
+int k_index(int k) { return k == 24 ? 0 : k == 22 ? 1 : k == 20 ? 2 : k == 18 ? 3 : -1; }
+
+// Fused FIXED decode (t3_decode_fused.hip): uniform k, 1-D, no beacon.  Returns T3_OK after launching, or 1 if not applicable.
+int decode_fixed_fused(const void* d_in, uint64_t n_in, const t3_cfg& cfg, const t3_layout& L, const ScrCycle& sc,
+                       void* d_out, uint64_t units, int to_pixels, uint32_t* d_fail, hipStream_t s) {
+    if (L.beacon_on || L.interleave2d || L.n_raw_words == 0) return 1;
+    for (int b = 1; b < 9; ++b) if (L.band_k[b] != L.band_k[0]) return 1;
+    const int k = L.band_k[0], ki = k_index(k);
+    if (!d_synd_lut[ki]) {
+        std::vector<uint32_t> img; build_syndrome_lut(k, img);
+        synd_lut_bytes[ki] = (uint32_t)img.size() * 4u;
+        HIPCHK(hipMalloc((void**)&d_synd_lut[ki], synd_lut_bytes[ki]));
+        HIPCHK(hipMemcpy(d_synd_lut[ki], img.data(), synd_lut_bytes[ki], hipMemcpyHostToDevice));
+    }
+    DecFxArgs a; memset(&a, 0, sizeof a);
+    a.in = (const uint8_t*)d_in; a.in_bytes = 9 * n_in; a.out = d_out; a.n_units = units; a.fail = d_fail;
+    a.tab = d_fxtab; a.lut = d_synd_lut[ki]; a.lut_bytes = synd_lut_bytes[ki];
+    a.k = (uint32_t)k; a.nb = 52; a.TS = 9u * 52u * (uint32_t)k; a.n_sym = (uint32_t)L.n_sym; a.hdr_syms = L.header_syms;
+    uint64_t maxb = 0;
+    for (int b = 0; b < 9; ++b) { a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b]; a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6); maxb = std::max<uint64_t>(maxb, L.band_blocks[b]); }
+    a.n_tiles = (uint32_t)((maxb + a.nb - 1) / a.nb);
+    a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
+    a.y_off = (kFxLut + a.lut_bytes + 15u) & ~15u;
+    a.o_off = (a.y_off + a.TS + 16u + 15u) & ~15u;
+    a.lds_bytes = a.o_off + (to_pixels ? (a.TS / 13u) * 18u : (a.TS / 26u) * 27u) + 64u;
+    const void* fn = nullptr;
+    switch (26 - k) {
+        case 2: fn = to_pixels ? (const void*)decode_fixed_kernel<2, true> : (const void*)decode_fixed_kernel<2, false>; break;
+        case 4: fn = to_pixels ? (const void*)decode_fixed_kernel<4, true> : (const void*)decode_fixed_kernel<4, false>; break;
+        case 6: fn = to_pixels ? (const void*)decode_fixed_kernel<6, true> : (const void*)decode_fixed_kernel<6, false>; break;
+        default: fn = to_pixels ? (const void*)decode_fixed_kernel<8, true> : (const void*)decode_fixed_kernel<8, false>; break;
+    }
+    static std::map<const void*, int> occ;
+    auto it = occ.find(fn);
+    if (it == occ.end()) {
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int o = 1; HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, 576, a.lds_bytes));
+        it = occ.emplace(fn, std::max(1, o)).first;
+    }
+    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(a.n_tiles, (uint32_t)(api_n_cu() * it->second)));
+    void* args[] = {(void*)&a};
+    HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(576), args, a.lds_bytes, s));
+    return T3_OK;
+}
 
 DevDiv to_dev(FastDiv f) { return DevDiv{f.mul, f.sh, f.d}; }
 unsigned grid_for(uint64_t items, unsigned block) { return (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, (items + block - 1) / block), 1u << 20); }
@@ -47,6 +97,12 @@ int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_r
         a.hdr_syms = 90; a.n_sym = L.n_sym;
         for (int b = 0; b < 9; ++b) { a.band_k[b] = L.band_k[b]; a.band_blocks[b] = L.band_blocks[b]; a.band_first[b] = total; a.band_off[b] = L.band_body_off[b]; total += L.band_blocks[b]; }
         use_syms = L.n_sym; n_words = n_raw;
+        const uint64_t funits = to_pixels ? 2 * n_words : n_words;
+        if (funits <= cap_units && (!to_pixels || ((uintptr_t)d_out & 15u) == 0) && getenv("T3HIP_GENERIC_DECODE") == nullptr) {
+            const int frc = decode_fixed_fused(d_in, n_in, cfg, L, sc, d_out, funits, to_pixels, d_fail, s);
+            if (frc == T3_OK) { *n_out = funits; return T3_OK; }
+            if (frc < 0) return frc;
+        }
     }
     a.total_blocks = total;
     const uint64_t units = to_pixels ? 2 * n_words : n_words;
@@ -89,6 +145,17 @@ int decode_init(const RsTables*) {
     HIPCHK(hipMalloc((void**)&d_zpow, z.size() * 4));
     HIPCHK(hipMemcpy(d_zpow, z.data(), z.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&d_crc_acc, 64));
+    {   // field tables of the fused decoder
+        const Field& F = field();
+        static const uint8_t want_exp[26] = {1, 3, 9, 5, 15, 23, 13, 17, 20, 4, 12, 14, 11, 2, 6, 18, 7, 21, 16, 26, 22, 10, 8, 24, 25, 19};
+        if (memcmp(F.t.exp, want_exp, 26) != 0) return T3_E_ARG;              // kExp in t3_decode_fused.hip is this table
+        FxTables T; memset(&T, 0, sizeof T);
+        memcpy(T.mul, F.t.mul, 729); memcpy(T.add, F.t.add, 729); memcpy(T.inv, F.t.inv, 27); memcpy(T.neg, F.t.neg, 27); memcpy(T.exp, F.t.exp, 26);
+        for (int x = 0; x < 27; ++x) for (int y = 0; y < 27; ++y) T.sub[x * 27 + y] = F.t.add[x * 27 + F.t.neg[y]];
+        for (int st = 0; st < 3; ++st) for (int c = 0; c < 27; ++c) T.descr[st][c] = (uint8_t)(8 * F.t.add[c * 27 + F.t.neg[13 * st]]);
+        HIPCHK(hipMalloc((void**)&d_fxtab, sizeof T));
+        HIPCHK(hipMemcpy(d_fxtab, &T, sizeof T, hipMemcpyHostToDevice));
+    }
     return T3_OK;
 }
 }  // namespace t3

@@ -40,10 +40,34 @@ struct CrcArgs {
     const uint32_t* zpow;                        // [kCrcPows][32] operator columns (device)
 };
 
+// Fused FIXED-mode decoder (uniform k, 1-D, no beacon): one tile = 9 bands x nb blocks -> a word-aligned slice of the
+// output (27 * Lq trits, Lq = nb * k a multiple of 26).  LDS: [band rows][FxTables][syndrome LUT][symbols Y][out staging].
+struct FxTables {                 // field tables the in-kernel corrector indexes (LDS resident)
+    uint8_t mul[729], add[729], sub[729];
+    uint8_t inv[27], neg[27], exp[26];
+    uint8_t descr[3][32];         // descr[s][c] = 8 * (c - (s,s,s) trit-wise): descrambled symbol, pre-scaled (LUT entry offset)
+    uint8_t pad_[37];
+};
+static_assert(sizeof(FxTables) == 2400, "FxTables layout");
+constexpr int kFxHdr = 512, kFxTab = kFxHdr, kFxLut = 3072;     // LDS byte offsets (kFxTab + 2400 <= kFxLut)
+struct DecFxArgs {
+    const uint8_t* in; uint64_t in_bytes;      // whole coded stream
+    void* out; uint64_t n_units;               // pixels (to_pixels) or words to emit
+    uint32_t* fail;
+    const FxTables* tab; const uint32_t* lut; uint32_t lut_bytes;
+    uint32_t k, nb, n_tiles, TS;               // nb blocks per band per tile (multiple of 13), TS = 9*nb*k stream symbols
+    uint32_t n_sym;                            // real stream symbols (the rest of the last blocks is zero padding)
+    uint32_t hdr_syms;
+    uint32_t band_blocks[9]; uint64_t band_body_off[9]; uint32_t band_boff6[9];
+    uint32_t cyc24, pre0, pre1;
+    uint32_t y_off, o_off, lds_bytes;
+};
+
 int decode_init(const RsTables* d_tab);
 
 #if defined(__HIPCC__)
 __global__ void dec_gather_rs_kernel(const DecArgs a);
+template <int R, bool TO_PIXELS> __global__ void decode_fixed_kernel(const DecFxArgs a);
 __global__ void dec_emit_kernel(const EmitArgs a);
 __global__ void rs_decode_blocks_kernel(uint8_t* code, uint64_t n_blocks, int k, int fixed, const RsTables* tab, uint8_t* data, uint8_t* ok);
 __global__ void inject_errors_kernel(uint8_t* syms, uint64_t n_blocks, uint32_t seed, int max_err);

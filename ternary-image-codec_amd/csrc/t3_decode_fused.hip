@@ -1,0 +1,313 @@
+// t3_decode_fused.hip — fused FIXED-mode ("v6c") decoder for gfx950: K3 syndromes + K4 Berlekamp–Massey / Chien / Forney +
+// K5 symbols -> pixels|words in ONE launch, tiled like the encoder (BASELINE config 5: decode with injected trit errors).
+// Replaces, for mode=FIXED / uniform k / 1-D / no beacon: descramble (OLD:938-947), per-band RS decode (OLD:963-991,
+// decode_block OLD:546-662 with the Forney sign fixed), the i%9 re-merge the reference omits, symbols -> 26-trit words
+// (OLD:1022-1040) and unpack_two_pixels (OLD:706-722).  Everything else goes through the generic kernels in t3_decode.hip.
+//
+// One lane = one RS block; wave w = band w.  Per tile:
+//   D1  7 aligned dword loads per lane (blocks are 26 B, 2-byte aligned) -> 26 symbols in registers
+//   D2  descramble through an 81-byte LDS table (result pre-scaled by 8), syndromes through a per-position LUT:
+//       6-bit SWAR trit fields, two conflict-free ds_read_b64 per symbol, one mod-3 fold per block
+//   D3  lanes with non-zero syndromes: Berlekamp–Massey (x*B kept shifted, fixed 8-coefficient registers), degree test,
+//       Chien over the 26 positions, Forney; field products/sums through 729-byte LDS tables
+//   D4  data symbols -> stream order in LDS (byte 9(mk+p)+b), <=3 corrected bytes patched in place
+//   D5  13 symbols -> 3 pixels (two triples per lane with packed 16-bit ops) or 26 symbols -> 3 words, staged in LDS,
+//       copied out with 16-byte coalesced stores.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/t3hip.h"
+#include "t3_decode.h"
+
+namespace t3 {
+
+extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+namespace {
+constexpr uint32_t MUL = kFxTab, ADD = kFxTab + 729, SUB = kFxTab + 1458, INV = kFxTab + 2187, NEG = INV + 27, EXP = NEG + 27, DSC = EXP + 26;
+static_assert(DSC == kFxTab + offsetof(FxTables, descr), "LDS table map");
+
+__device__ __forceinline__ uint32_t gfm(uint32_t a, uint32_t b) { return lds[MUL + a * 27u + b]; }
+__device__ __forceinline__ uint32_t gfa(uint32_t a, uint32_t b) { return lds[ADD + a * 27u + b]; }
+__device__ __forceinline__ uint32_t gfs(uint32_t a, uint32_t b) { return lds[SUB + a * 27u + b]; }
+
+__device__ __forceinline__ uint32_t mod3x5(uint32_t x) {          // five 6-bit fields (<= 63) -> {0,1,2}
+    x = (x & 0x030C30C3u) + ((x >> 2) & 0x0F3CF3CFu);
+    x = (x & 0x030C30C3u) + ((x >> 2) & 0x030C30C3u);
+    x = (x & 0x030C30C3u) + ((x >> 2) & 0x01041041u);
+    const uint32_t t = x & (x >> 1) & 0x01041041u;
+    return x - (t | (t << 1));
+}
+__device__ __forceinline__ uint32_t d3(uint32_t x)  { return __umul24(x, 171u) >> 9; }
+__device__ __forceinline__ uint32_t d9(uint32_t x)  { return __umul24(x, 228u) >> 11; }
+__device__ __forceinline__ uint32_t d27(uint32_t x) { return __umul24(x, 152u) >> 12; }
+
+// alpha^i, the field's antilog table (checked against the host field at init: t3_api_decode.cpp)
+__device__ constexpr uint8_t kExp[26] = {1, 3, 9, 5, 15, 23, 13, 17, 20, 4, 12, 14, 11, 2, 6, 18, 7, 21, 16, 26, 22, 10, 8, 24, 25, 19};
+
+struct Fix { uint32_t np; uint32_t pos[4]; uint32_t mag[4]; };   // up to t = 4 corrections (RS(26,18))
+
+// decode_block after the syndromes (OLD:567-659), FIXED flavour, for R syndromes and T = R/2.  Polynomials live in fixed
+// zero-padded registers, which is equivalent to the reference's growing vectors (only coefficient VALUES matter once the
+// Horner loops start at the true degree).  Returns false for an uncorrectable block.
+template <int R>
+__device__ __forceinline__ bool fx_correct(const uint32_t* S, Fix& fx) {
+    constexpr int T = R / 2, NP = R + 2;
+    uint32_t sg[NP], bx[NP];                                        // sigma, and x^m * B (B shifted as the reference's xmdB)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { sg[i] = 0; bx[i] = 0; }
+    sg[0] = 1; bx[1] = 1;
+    uint32_t L = 0;
+#pragma unroll
+    for (int n = 0; n < R; ++n) {
+        uint32_t d = S[n];
+#pragma unroll
+        for (int i = 1; i <= n; ++i) d = gfa(d, gfm(sg[i], S[n - i]));      // sigma[i] = 0 beyond L: same sum as OLD:572
+        const bool upd = d != 0 && 2u * L <= (uint32_t)n;
+        const uint32_t iv = lds[INV + d];
+        uint32_t nb[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (i <= n + 1) {
+                const uint32_t old = sg[i];
+                sg[i] = gfs(old, gfm(d, bx[i]));                             // d == 0: product 0, unchanged (OLD:573-587)
+                nb[i] = gfm(old, iv);                                        // T * inv(delta) (OLD:590-592)
+            } else nb[i] = 0;
+        }
+        if (upd) L = (uint32_t)n + 1u - L;
+#pragma unroll
+        for (int i = NP - 1; i >= 1; --i) bx[i] = upd ? nb[i - 1] : bx[i - 1];   // next x^m * B
+        bx[0] = 0;
+    }
+    uint32_t deg = 0;
+#pragma unroll
+    for (int i = 1; i < NP; ++i) if (sg[i] != 0) deg = (uint32_t)i;
+    fx.np = 0;
+    if (deg > (uint32_t)T) return false;                                      // then #roots > t or #roots != deg (OLD:624 + FIXED rule)
+    // Chien (OLD:611-623): sigma(alpha^-i) for the 26 positions, Horner from degree T (leading zeros are harmless)
+    uint32_t roots = 0;
+#pragma unroll
+    for (int i = 0; i < 26; ++i) {
+        const uint32_t x = kExp[i == 0 ? 0 : 26 - i];
+        uint32_t acc = sg[T];
+#pragma unroll
+        for (int q = T - 1; q >= 0; --q) acc = gfa(gfm(acc, x), sg[q]);
+        roots |= (acc == 0 ? 1u : 0u) << i;
+    }
+    const uint32_t np = (uint32_t)__popc(roots);
+    if (np != deg) return false;
+    // Omega = S(x) sigma(x) mod x^R (OLD:606-610), sigma' in characteristic 3 (OLD:625-641): sigma1 + 2 sigma2 x (+ 4th, 5th for R=8)
+    uint32_t Om[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        uint32_t acc = S[q];                                                   // j = 0 term, sigma0 = 1
+#pragma unroll
+        for (int j = 1; j <= T; ++j) if (j <= q) acc = gfa(acc, gfm(S[q - j], sg[j]));
+        Om[q] = acc;
+    }
+    uint32_t r = roots;
+#pragma unroll
+    for (int e = 0; e < T; ++e) {
+        if ((uint32_t)e < np) {
+            const uint32_t p = (uint32_t)__ffs((int)r) - 1u; r &= r - 1u;
+            const uint32_t xi = lds[EXP + (p == 0 ? 0u : 26u - p)];
+            uint32_t num = Om[R - 1];
+#pragma unroll
+            for (int q = R - 2; q >= 0; --q) num = gfa(gfm(num, xi), Om[q]);
+            uint32_t den = gfa(sg[1], gfm(gfa(sg[2], sg[2]), xi));             // sigma1 + 2 sigma2 x  (x^2 term of sigma' is 3 sigma3 = 0)
+            if constexpr (T >= 4) den = gfa(den, gfm(gfm(gfm(sg[4], xi), xi), xi));   // + 4 sigma4 x^3 = sigma4 x^3
+            if (den == 0) return false;                                        // OLD:656
+            fx.pos[e] = p; fx.mag[e] = gfm(lds[NEG + num], lds[INV + den]);    // OLD:657; FIXED subtracts it
+        }
+    }
+    fx.np = np;
+    return true;
+}
+
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 pd3(u16x2 x)  { return (x * (uint16_t)171) >> (uint16_t)9; }
+__device__ __forceinline__ u16x2 pd9(u16x2 x)  { return (x * (uint16_t)228) >> (uint16_t)11; }
+__device__ __forceinline__ uint32_t bits(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+struct Row { uint32_t blocks, boff6; uint64_t body_off; };
+__device__ __forceinline__ Row row(uint32_t b) { return *(const Row*)(lds + 16u * b); }
+}  // namespace
+
+template <int R, bool TO_PIXELS>
+__global__ __launch_bounds__(640, 5) void decode_fixed_kernel(const DecFxArgs a) {
+    constexpr uint32_t K = 26 - R, SLAB = R == 8 ? 768u : 512u;
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // constants -> LDS
+    if (tid == 0) {
+#pragma unroll
+        for (int b = 0; b < 9; ++b) { Row r; r.blocks = a.band_blocks[b]; r.boff6 = a.band_boff6[b]; r.body_off = a.band_body_off[b]; *(Row*)(lds + 16 * b) = r; }
+    }
+    for (uint32_t i = tid * 16u; i < (uint32_t)sizeof(FxTables); i += nthr * 16u) *(uint4*)(lds + kFxTab + i) = *(const uint4*)((const uint8_t*)a.tab + i);
+    for (uint32_t i = tid * 16u; i < a.lut_bytes; i += nthr * 16u) *(uint4*)(lds + kFxLut + i) = *(const uint4*)((const uint8_t*)a.lut + i);
+    __syncthreads();
+
+    const uint32_t units_tile = TO_PIXELS ? (a.TS / 13u) * 3u : (a.TS / 26u) * 3u;       // pixels / words produced per tile
+    for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        // ---------------- D1-D4: one lane = one block of band `wave` ----------------
+        if (wave < 9u) {
+            const uint32_t b = wave, m = lane;
+            const Row rw = row(b);
+            const uint64_t mg = (uint64_t)tile * a.nb + m;
+            if (m < a.nb && mg < rw.blocks) {
+                const uint8_t* g = a.in + a.hdr_syms + rw.body_off + 26ull * mg;
+                const uint32_t sh = ((uint32_t)(uintptr_t)g & 3u) * 8u;
+                uint32_t w[7];
+                if (g + 28 <= a.in + a.in_bytes) {
+                    const uint32_t* p = (const uint32_t*)((uintptr_t)g & ~(uintptr_t)3);
+                    uint32_t dw[7];
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) dw[i] = p[i];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) w[i] = __builtin_amdgcn_alignbit(dw[i + 1], dw[i], sh);
+                    w[6] = dw[6] >> sh;
+                } else {                                                       // last bytes of the stream: no over-read
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) w[i] = 0;
+#pragma unroll
+                    for (int i = 0; i < 26; ++i) w[i >> 2] |= (uint32_t)g[i] << (8 * (i & 3));
+                }
+                // scrambler state per residue class of the position (6-periodic); the first two body symbols are special
+                const uint32_t c0 = (rw.boff6 + 2u * (uint32_t)(mg % 3u)) % 6u;
+                uint32_t dbase[6];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) dbase[q] = DSC + 32u * ((a.cyc24 >> (2u * (c0 + q))) & 3u);
+                const bool first = rw.body_off == 0 && mg == 0;
+                uint32_t c[26]; bool big = false;
+#pragma unroll
+                for (int i = 0; i < 26; ++i) { c[i] = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu; big |= c[i] >= 27u; }
+                if (__builtin_amdgcn_ballot_w64(big) != 0) {
+#pragma unroll
+                    for (int i = 0; i < 26; ++i) c[i] -= 27u * d27(c[i]);           // unpack3 semantics for non-canonical bytes
+                }
+                uint32_t d8[26];
+#pragma unroll
+                for (int i = 0; i < 26; ++i) {
+                    uint32_t base = dbase[i % 6];
+                    if (i < 2 && first) base = DSC + 32u * (i == 0 ? a.pre0 : a.pre1);
+                    d8[i] = lds[base + c[i]];                                      // descrambled symbol * 8
+                }
+                uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 26; ++i) {
+                    const uint2 A = *(const uint2*)(lds + kFxLut + i * SLAB + d8[i]);
+                    const uint2 B = *(const uint2*)(lds + kFxLut + i * SLAB + 256u + d8[i]);
+                    acc0 += A.x; acc1 += A.y; acc2 += B.x; acc3 += B.y;
+                    if constexpr (R == 8) acc4 += *(const uint32_t*)(lds + kFxLut + i * SLAB + 512u + d8[i]);
+                    if (i % 9 == 8) { asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "+v"(acc4)); __builtin_amdgcn_sched_barrier(0); }
+                }
+                const uint32_t x0 = mod3x5(acc0), x1 = mod3x5(acc1), x2 = mod3x5(acc2);
+                const uint32_t Sm = x0 + 3u * x1 + 9u * x2;
+                uint32_t S[R];
+                constexpr int NMAIN = R < 5 ? R : 5;
+#pragma unroll
+                for (int j = 0; j < NMAIN; ++j) S[j] = (Sm >> (6 * j)) & 63u;
+                uint32_t any = Sm & 0x3FFFFFFFu;
+                if constexpr (R == 2) any = Sm & 0xFFFu;
+                if constexpr (R == 4) any = Sm & 0xFFFFFFu;
+                if constexpr (R >= 6) {
+                    const uint32_t x3 = mod3x5(acc3);
+                    S[5] = (x3 & 63u) + 3u * ((x3 >> 6) & 63u) + 9u * ((x3 >> 12) & 63u);
+                    any |= S[5];
+                    if constexpr (R == 8) {
+                        const uint32_t x4 = mod3x5(acc4);
+                        S[6] = ((x3 >> 18) & 63u) + 3u * ((x3 >> 24) & 63u) + 9u * (x4 & 63u);
+                        S[7] = ((x4 >> 6) & 63u) + 3u * ((x4 >> 12) & 63u) + 9u * ((x4 >> 18) & 63u);
+                        any |= S[6] | S[7];
+                    }
+                }
+                // data symbols -> stream order (the zero padding of a band's last block is not stored)
+                const uint32_t yb = a.y_off + b + 9u * K * m;
+#pragma unroll
+                for (uint32_t p = 0; p < K; ++p) lds[yb + 9u * p] = (uint8_t)(d8[p] >> 3);
+                if (any != 0) {                                                   // OLD:562: all-zero syndromes -> nothing to do
+                    Fix fx;
+                    if (!fx_correct<R>(S, fx)) atomicAdd(a.fail, 1u);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < R / 2; ++e)
+                            if ((uint32_t)e < fx.np && fx.pos[e] < K) { const uint32_t ad = yb + 9u * fx.pos[e]; lds[ad] = (uint8_t)gfs(lds[ad], fx.mag[e]); }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- D5: symbols -> output units, staged in LDS ----------------
+        const uint64_t unit0 = (uint64_t)tile * units_tile;
+        const uint32_t n_here = (uint32_t)min((uint64_t)units_tile, a.n_units > unit0 ? a.n_units - unit0 : 0ull);
+        if constexpr (TO_PIXELS) {
+            const uint32_t ntr = a.TS / 13u;                                       // triples in the tile
+            for (uint32_t j = tid; 2u * j < ntr; j += nthr) {                       // lane: triples 2j, 2j+1 packed in 16-bit halves
+                const uint32_t ya = a.y_off + 26u * j;
+                u16x2 s[13];
+#pragma unroll
+                for (int i = 0; i < 13; ++i) s[i] = u16x2{lds[ya + i], lds[ya + 13 + i]};
+                u16x2 q, t, Y0, B0, R0, Y1, B1, R1, Y2, B2, R2;                    // inverse of the encoder's splice (unpack_two_pixels OLD:706-722)
+                q = pd9(s[1]);  Y0 = s[0] + (s[1] - q * (uint16_t)9) * (uint16_t)27;  B0 = q + s[2] * (uint16_t)3;
+                q = pd3(s[4]);  R0 = s[3] + (s[4] - q * (uint16_t)3) * (uint16_t)27;  Y1 = q + s[5] * (uint16_t)9;
+                q = pd3(s[7]);  B1 = s[6] + (s[7] - q * (uint16_t)3) * (uint16_t)27;
+                t = pd9(s[8]);  R1 = q + (s[8] - t * (uint16_t)9) * (uint16_t)9;
+                q = pd3(s[10]); Y2 = t + s[9] * (uint16_t)3 + (s[10] - q * (uint16_t)3) * (uint16_t)81;
+                t = pd9(s[11]); B2 = q + (s[11] - t * (uint16_t)9) * (uint16_t)9;      R2 = t + s[12] * (uint16_t)3;
+                const u16x2 px[9] = {Y0, B0 - (uint16_t)40, R0 - (uint16_t)40, Y1, B1 - (uint16_t)40, R1 - (uint16_t)40, Y2, B2 - (uint16_t)40, R2 - (uint16_t)40};
+                const uint32_t oa = a.o_off + 36u * j;                              // triple 2j at +0, 2j+1 at +18
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { const uint32_t v = bits(px[i]); *(uint16_t*)(lds + oa + 2 * i) = (uint16_t)v; *(uint16_t*)(lds + oa + 18 + 2 * i) = (uint16_t)(v >> 16); }
+            }
+        } else {
+            const uint32_t ng = a.TS / 26u;                                        // groups of 26 symbols -> 3 words (OLD:1022-1040)
+            for (uint32_t j = tid; j < ng; j += nthr) {
+                const uint32_t ya = a.y_off + 26u * j;
+                uint32_t s[26], o[27];
+#pragma unroll
+                for (int i = 0; i < 26; ++i) s[i] = lds[ya + i];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = s[i];
+                o[8] = s[8] - 9u * d9(s[8]);                                        // trits 24,25 of word 0, trit 26 = 0
+                uint32_t carry = d9(s[8]);                                          // trit 0 of word 1
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const uint32_t lo = s[9 + i] - 9u * d9(s[9 + i]); o[9 + i] = carry + 3u * lo; carry = d9(s[9 + i]); }
+                { const uint32_t lo = s[17] - 3u * d3(s[17]); o[17] = carry + 3u * lo; }            // trits 24,25 of word 1 (trit 25 = digit 0 of s17)
+                uint32_t car2 = d3(s[17]);                                          // trits 0,1 of word 2
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const uint32_t lo = s[18 + i] - 3u * d3(s[18 + i]); o[18 + i] = car2 + 9u * lo; car2 = d3(s[18 + i]); }
+                o[26] = car2;                                                       // trits 24,25 of word 2
+                const uint32_t oa = a.o_off + 27u * j;
+#pragma unroll
+                for (int i = 0; i < 27; ++i) lds[oa + i] = (uint8_t)o[i];
+            }
+        }
+        __syncthreads();
+        // coalesced copy-out of the tile's units
+        {
+            constexpr uint32_t UB = TO_PIXELS ? 6u : 9u;
+            const uint32_t nbytes = n_here * UB;
+            uint8_t* g = (uint8_t*)a.out + unit0 * UB;
+            const uint32_t mis = (uint32_t)(uintptr_t)g & 15u;                       // words: tile starts are only 8-byte aligned
+            const uint32_t head = min(nbytes, (16u - mis) & 15u);
+            for (uint32_t i = tid; i < head; i += nthr) g[i] = lds[a.o_off + i];
+            const uint32_t nmain = (nbytes - head) >> 4;
+            if (head % 4u == 0) {
+                for (uint32_t i = tid; i < nmain; i += nthr) {
+                    const uint32_t* s4 = (const uint32_t*)(lds + a.o_off + head + 16u * i);
+                    *(uint4*)(g + head + 16u * i) = make_uint4(s4[0], s4[1], s4[2], s4[3]);
+                }
+            } else {
+                for (uint32_t i = tid; i < 16u * nmain; i += nthr) g[head + i] = lds[a.o_off + head + i];
+            }
+            for (uint32_t i = head + 16u * nmain + tid; i < nbytes; i += nthr) g[i] = lds[a.o_off + i];
+        }
+        __syncthreads();
+    }
+}
+
+template __global__ void decode_fixed_kernel<2, true>(const DecFxArgs);  template __global__ void decode_fixed_kernel<2, false>(const DecFxArgs);
+template __global__ void decode_fixed_kernel<4, true>(const DecFxArgs);  template __global__ void decode_fixed_kernel<4, false>(const DecFxArgs);
+template __global__ void decode_fixed_kernel<6, true>(const DecFxArgs);  template __global__ void decode_fixed_kernel<6, false>(const DecFxArgs);
+template __global__ void decode_fixed_kernel<8, true>(const DecFxArgs);  template __global__ void decode_fixed_kernel<8, false>(const DecFxArgs);
+
+}  // namespace t3

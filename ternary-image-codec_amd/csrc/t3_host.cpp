@@ -164,6 +164,28 @@ void build_encode_lut(int k, int mode, std::vector<uint32_t>& image) {
     }
 }
 
+int syndrome_lut_slab(int k) { return 26 - k == 8 ? 768 : 512; }
+void build_syndrome_lut(int k, std::vector<uint32_t>& image) {
+    const Field& F = field(); RsView v = rs_view(F.t);
+    const int r = 26 - k, nmain = r < 5 ? r : 5, slab = syndrome_lut_slab(k);
+    image.assign((size_t)26 * slab / 4, 0u);
+    for (int i = 0; i < 26; ++i) {
+        uint32_t* sl = image.data() + (size_t)i * slab / 4;
+        for (int c = 0; c < 27; ++c) {
+            uint32_t dw[6] = {0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < r; ++j) {
+                const int y = v.M((uint8_t)c, v.P((j + 1) * i));
+                const int tr[3] = {y % 3, (y / 3) % 3, y / 9};
+                if (j < nmain) for (int q = 0; q < 3; ++q) dw[q] |= (uint32_t)tr[q] << (6 * j);
+                else for (int q = 0; q < 3; ++q) { const int f = 3 * (j - 5) + q; dw[3 + f / 5] |= (uint32_t)tr[q] << (6 * (f % 5)); }
+            }
+            sl[2 * c] = dw[0]; sl[2 * c + 1] = dw[1];
+            sl[64 + 2 * c] = dw[2]; sl[64 + 2 * c + 1] = dw[3];
+            if (r == 8) { sl[128 + 2 * c] = dw[4]; sl[128 + 2 * c + 1] = 0; }
+        }
+    }
+}
+
 // ---- scrambler ----------------------------------------------------------------------------------------
 ScrCycle scrambler_cycle_from_next(const uint8_t next[3], uint32_t s0) {
     ScrCycle c; memset(&c, 0, sizeof c);

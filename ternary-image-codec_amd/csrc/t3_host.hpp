@@ -50,6 +50,12 @@ LutGeom lut_geom(int k);
 //   [A: 27 x {dw0,dw1}] [B (r=8 only): 27 x {dw2,dw3}] [V_0][V_1][V_2], V_s: 27 x {dw2, dw3|img<<24} (r=6) or {dwv|img<<24, 0}.
 void build_encode_lut(int k, int mode, std::vector<uint32_t>& image);
 
+// Syndrome LUT for the fused decoder: position i (0..25), symbol c -> c * alpha^{(j+1) i} for j < r as 6-bit SWAR trit
+// fields, same dword layout as the encode LUT ("main" parities -> syndromes 0..4 plane-major, extras after), two 8-byte
+// tables per position (A: {dw0,dw1} at +0, B: {dw2,dw3} at +256; r=8 adds C: {dw4,0} at +512). 26 * slab bytes.
+int  syndrome_lut_slab(int k);
+void build_syndrome_lut(int k, std::vector<uint32_t>& image);
+
 // ---- scrambler (OLD:77-94) ------------------------------------------------------------------------
 struct ScrCycle {
     uint8_t pre[2];      // state applied to body symbols 0 and 1
