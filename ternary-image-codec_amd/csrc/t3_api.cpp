@@ -90,17 +90,19 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     // pick q (even): tile = 9*Lk*q stream symbols; band b then owns Lk*q/k_b blocks = that/2 lane pairs
     double best_score = -1; uint32_t best_q = 0;
     for (int pass = 0; pass < 2 && !best_q; ++pass) {
-        const uint32_t budget = pass == 0 ? 80u * 1024u : 160u * 1024u;
+        const uint32_t budget = pass == 0 ? 53u * 1024u : 160u * 1024u;     // <= 53 KiB: three workgroups per CU
         for (uint32_t q = 2; q <= 4096; q += 2) {
             const uint64_t Lq = Lk * q; if (9 * Lq > 60000) break;
             uint32_t waves = 0, blocks_total = 0, outb = 0;
             for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) {
                 const uint32_t nb = (uint32_t)(Lq / L.band_k[b]);
-                waves += (nb + 63) / 64; blocks_total += nb; outb += round16(26 * nb + 32);
+                blocks_total += nb; outb += round16(26 * nb + 32);
             }
-            if (waves > (uint32_t)kMaxWaves) break;
+            waves = (blocks_total + 63) / 64;                          // lanes are dealt to blocks linearly across bands
+            if (waves > (pass == 0 ? 8u : (uint32_t)kMaxWaves)) break;   // pass 0: 512-thread workgroups, three per CU
             const uint32_t groups = (uint32_t)(9 * Lq / GS) + 6, stage = groups * GB + 1024 + 32;   // +1 KiB: LDS-DMA pieces are whole
-            const uint32_t total = kLdsHdr + round16(lut_bytes) + round16((uint32_t)(9 * Lq)) + 16 + 2 * std::max(round16(stage), outb);
+            const uint32_t total = kLdsHdr + round16(lut_bytes) + round16((uint32_t)(9 * Lq)) + 16 + round16(stage);
+            (void)outb;
             if (total > budget) break;
             const double util = (double)blocks_total / (64.0 * waves);
             const double score = util + 1e-7 * (double)Lq;          // utilisation first, then the larger tile
@@ -122,14 +124,13 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
         if (!(band_mask >> b & 1)) { a.band_nb_tile[b] = 0; a.band_blocks[b] = 0; continue; }
         const uint32_t nb = Lq / L.band_k[b];
         a.band_nb_tile[b] = nb; a.band_out_off[b] = outb; outb += round16(26 * nb + 32);
-        for (uint32_t w = 0; w < (nb + 63) / 64; ++w) { a.wave_band[nw] = b; a.wave_blk0[nw] = 64 * w; ++nw; }
+        nw += nb;
         n_tiles = std::max<uint32_t>(n_tiles, (uint32_t)((L.band_blocks[b] + nb - 1) / nb));
     }
-    a.n_waves = nw; a.n_tiles = n_tiles;
-    a.p3_private = (nw == 9 && band_mask == 0x1FF) ? 1u : 0u;
-    for (uint32_t w = 0; w < nw && a.p3_private; ++w) if (a.wave_band[w] != w) a.p3_private = 0;
-    a.stage_stride = std::max(round16(a.stage_groups * GB + 1024 + 32), outb);
-    a.lds_bytes = a.stage_off + 2 * a.stage_stride;
+    a.n_items = nw; a.n_tiles = n_tiles;
+    { uint32_t acc = 0; for (int b = 0; b < 9; ++b) { a.band_first[b] = acc; acc += a.band_nb_tile[b]; } a.band_first[9] = acc; }
+    a.stage_stride = round16(a.stage_groups * GB + 1024 + 32);
+    a.lds_bytes = a.stage_off + a.stage_stride;
     a.n_sym = (uint32_t)L.n_sym;
     const ScrCycle sc = scrambler_cycle(cfg.seed_a, cfg.seed_b, cfg.seed_s0);
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
@@ -139,9 +140,10 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
         a.il_w = cfg.tile_w; a.il_A = (uint32_t)std::min<uint64_t>(A, std::max<uint64_t>(L.n_sym, 1));
         a.div_A = to_dev(fastdiv(a.il_A)); a.div_w = to_dev(fastdiv(a.il_w));
     }
-    out.block = 64u * std::max<uint32_t>(nw, 4u);
+    out.block = 64u * std::max<uint32_t>((nw + 63) / 64, 4u);
     out.rsel = 0;
-    { int k0 = 0; bool same = true; for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) { if (!k0) k0 = L.band_k[b]; else if (k0 != L.band_k[b]) same = false; } if (same && k0) out.rsel = 26 - k0; }
+    { int k0 = 0; bool same = true; for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) { if (!k0) k0 = L.band_k[b]; else if (k0 != L.band_k[b]) same = false; } if (same && k0 && band_mask == 0x1FF) out.rsel = 26 - k0; }
+    a.nb_uniform = out.rsel ? a.band_nb_tile[0] : 0u; a.div_nb = to_dev(fastdiv(a.nb_uniform ? a.nb_uniform : 1u));
     return true;
 }
 
@@ -176,6 +178,10 @@ int launch_fn(const void* fn, const EncLaunch& e, hipStream_t s) {
         for (uint32_t w = 0; w < grid; ++w) for (int i = 0; i < 8; ++i) acc[i] += (double)h[8 * w + i];
         fprintf(stderr, "[t3 stamps] grid=%u tiles=%u  mean cycles/WG: stage=%.0f p1=%.0f p2=%.0f p3=%.0f total=%.0f  clock=%.3f GHz\n", grid, e.a.n_tiles,
                 acc[0] / grid, acc[1] / grid, acc[2] / grid, acc[3] / grid, acc[4] / grid, acc[4] / acc[5] * 0.1);
+        { uint64_t s0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0; for (uint32_t w = 0; w < grid; ++w) { const uint64_t st = h[8 * w + 3], en = st + h[8 * w + 5]; s0 = std::min(s0, st); s1 = std::max(s1, st); e0 = std::min(e0, en); e1 = std::max(e1, en); }
+          int late = 0; for (uint32_t w = 0; w < grid; ++w) if (h[8 * w + 3] - s0 > 1000) ++late;
+          fprintf(stderr, "[t3 stamps]   timeline (us from first start): last start=%.2f first end=%.2f last end=%.2f  WGs starting >10us late=%d\n", (s1 - s0) * 0.01, (e0 - s0) * 0.01, (e1 - s0) * 0.01, late);
+          fprintf(stderr, "[t3 stamps]   lds_bytes=%u block=%u\n", e.a.lds_bytes, e.block); }
         fprintf(stderr, "[t3 stamps]   p1 split (wave 0): prefetch issue=%.0f convert=%.0f barrier wait=%.0f\n", acc[6] / grid, acc[7] / grid, acc[1] / grid);
     }
 #endif

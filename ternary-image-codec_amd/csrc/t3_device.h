@@ -35,10 +35,10 @@ struct EncArgs {
     uint32_t  band_out_off[9];      // byte offset of the band's staging run inside the current stage buffer (16-B aligned, slack)
     uint32_t  band_boff6[9];        // (band_body_off + 4) % 6 : scrambler cycle phase of the band's first symbol
     uint64_t  band_body_off[9];
-    uint32_t  wave_band[kMaxWaves]; // phase-2 role of each wave: band ...
-    uint32_t  wave_blk0[kMaxWaves]; // ... and first tile-local block it covers (one block per lane)
-    uint32_t  n_waves;
-    uint32_t  p3_private;           // 1 when wave w alone produces band w (its copy-out needs no workgroup barrier)
+    uint32_t  band_first[10];       // phase-2 work item -> band: band b owns items [band_first[b], band_first[b+1]); one lane = one block
+    uint32_t  n_items;              // = band_first[9] = sum of blocks per tile
+    uint32_t  nb_uniform;           // blocks per band per tile when all bands share k (item / nb_uniform = band), else 0
+    DevDiv    div_nb;
     uint32_t  sym_off, stage_off, lds_bytes;   // LDS carve-up: [hdr][LUT][symbols][stage 0][stage 1]
     uint32_t  stage_stride;         // bytes between the two input stage buffers (out staging aliases the current one)
     uint32_t  stage_groups;         // capacity of one input stage buffer, in lane groups

@@ -142,7 +142,7 @@ template <> struct LutGeo<8> { static constexpr uint32_t SLAB = 1280, VOFF = 512
 struct Blk26 { uint32_t w[7]; };   // 26 output bytes, little-endian packed (w[6] holds 2)
 struct BandRow { uint32_t k, nbt, blocks, lut_off, out_off, boff6; uint64_t body_off; };   // 32 B, LDS header row b
 __device__ __forceinline__ BandRow band_row(uint32_t b) { return *(const BandRow*)(lds + 32u * b); }
-__device__ __forceinline__ uint32_t wave_role(uint32_t wave, uint32_t f) { return *(const uint32_t*)(lds + 288u + 8u * wave + 4u * f); }
+__device__ __forceinline__ uint32_t band_first(uint32_t b) { return *(const uint32_t*)(lds + 288u + 4u * b); }
 
 __device__ __forceinline__ uint32_t add13(uint32_t d, uint32_t s) {   // d + (s,s,s) trit-wise (scramble_symbol OLD:81-87)
     const uint32_t q1 = div3(d), q2 = div9(d);
@@ -252,38 +252,28 @@ __device__ __forceinline__ uint32_t il_row_end(uint32_t u, const EncArgs& a) {  
     return base + r * a.il_w + min(a.il_w, take - r * a.il_w);
 }
 
+// Phase 2 for one lane: encode block m of band b and store its 26 bytes straight to the band's run in global memory.
+// A block starts 2-byte aligned (header and band offsets are even), so it is exactly six aligned dwords plus one short —
+// at the front when the block starts at 2 (mod 4), at the back otherwise: 7 stores per lane, no overlap with the
+// neighbour blocks, no LDS staging.  Consecutive lanes hold consecutive blocks, so a wave's seven store instructions
+// cover one contiguous 1664-byte run (13 cache lines).
 template <int R, bool FIXED_LUT>
-__device__ __forceinline__ void phase2_band(const EncArgs& a, uint32_t stage, uint32_t tile, uint32_t b, uint32_t m, uint32_t nbt, uint32_t lane) {
+__device__ __forceinline__ bool phase2_band(const EncArgs& a, uint32_t tile, uint32_t b, uint32_t m, uint32_t nbt) {
     constexpr uint32_t K = 26 - R;
     const uint32_t mg = tile * nbt + m;
     const BandRow r = band_row(b);
-    const bool valid = m < nbt && mg < r.blocks;
-    Blk26 o;
+    if (!(m < nbt && mg < r.blocks)) return false;
+    const uint32_t c0 = (r.boff6 + 2u * (mg % 3u)) % 6u;                             // 26 == 2 (mod 6)
+    const Blk26 o = encode_block<R, FIXED_LUT>(a.sym_off + b + 9u * K * m, r.lut_off, c0, r.body_off == 0 && mg == 0, a);
+    uint8_t* G = a.body_out + r.body_off + 26ull * mg;
+    const bool al = ((uint32_t)(uintptr_t)G & 2u) == 0;
+    uint32_t* base = (uint32_t*)(G + (al ? 0 : 2));                                    // six aligned dwords
 #pragma unroll
-    for (int i = 0; i < 7; ++i) o.w[i] = 0;
-    if (valid) {
-        const uint32_t c0 = (r.boff6 + 2u * (mg % 3u)) % 6u;                         // 26 == 2 (mod 6)
-        o = encode_block<R, FIXED_LUT>(a.sym_off + b + 9u * K * m, r.lut_off, c0, r.body_off == 0 && mg == 0, a);
-    }
-    // The staging image is placed so that LDS address == global address (mod 16): the copy-out is then aligned on both
-    // sides.  Block starts are only 2-byte aligned, so every lane stores the 7 aligned dwords that cover its 26 bytes and
-    // takes the 2 bytes it shares with its neighbour through a lane shuffle (both lanes store the same value there).
-    const uint32_t nxt0 = __shfl_down(o.w[0], 1), prv6 = __shfl_up(o.w[6], 1);
-    if (!valid) return;
-    const uint64_t gaddr = (uint64_t)(uintptr_t)a.body_out + r.body_off + 26ull * ((uint64_t)tile * nbt);
-    const uint32_t off = stage + r.out_off + ((uint32_t)gaddr & 15u) + 26u * m;
-    const bool al = (off & 2u) == 0;
-    const uint32_t A0 = off & ~3u;
-    uint32_t D[7];
-    D[0] = al ? o.w[0] : ((prv6 & 0xFFFFu) | (o.w[0] << 16));
-#pragma unroll
-    for (int i = 1; i < 6; ++i) D[i] = al ? o.w[i] : ((o.w[i - 1] >> 16) | (o.w[i] << 16));
-    D[6] = al ? ((o.w[6] & 0xFFFFu) | (nxt0 << 16)) : ((o.w[5] >> 16) | (o.w[6] << 16));
-#pragma unroll
-    for (int i = 1; i < 6; ++i) *(uint32_t*)(lds + A0 + 4 * i) = D[i];
-    if (al || lane > 0) *(uint32_t*)(lds + A0) = D[0]; else *(uint16_t*)(lds + A0 + 2) = (uint16_t)(D[0] >> 16);
-    if (!al || lane < 63) *(uint32_t*)(lds + A0 + 24) = D[6]; else *(uint16_t*)(lds + A0 + 24) = (uint16_t)D[6];
+    for (int i = 0; i < 6; ++i) base[i] = al ? o.w[i] : ((o.w[i] >> 16) | (o.w[i + 1] << 16));
+    *(uint16_t*)(G + (al ? 24 : 0)) = (uint16_t)(al ? o.w[6] : o.w[0]);                // and the remaining short
+    return true;
 }
+constexpr uint32_t kP2Stores = 7;   // global store instructions a wave issues in phase 2 (counted vmcnt at the tile top)
 
 // Stage the input bytes of lane groups [g_lo, g_hi) into the stage buffer at LDS offset `stage`: image byte x = input
 // byte b0 + x with b0 = 16-aligned start of group g_lo.  Whole 1-KiB pieces inside the real data go by LDS-DMA
@@ -496,6 +486,7 @@ __device__ __forceinline__ void barrier_input(uint32_t younger) {
         case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
         case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
         default: barrier_all(); break;
     }
 }
@@ -514,11 +505,11 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 #pragma unroll
         for (int b = 0; b < 9; ++b) {
             BandRow r; r.k = a.band_k[b]; r.nbt = a.band_nb_tile[b]; r.blocks = a.band_blocks[b]; r.lut_off = a.band_lut_off[b];
-            r.out_off = a.band_out_off[b]; r.boff6 = a.band_boff6[b]; r.body_off = a.band_body_off[b];
+            r.out_off = 0; r.boff6 = a.band_boff6[b]; r.body_off = a.band_body_off[b];
             *(BandRow*)(lds + 32 * b) = r;
         }
 #pragma unroll
-        for (int w = 0; w < kMaxWaves; ++w) { *(uint32_t*)(lds + 288 + 8 * w) = a.wave_band[w]; *(uint32_t*)(lds + 292 + 8 * w) = a.wave_blk0[w]; }
+        for (int b = 0; b < 10; ++b) *(uint32_t*)(lds + 288 + 4 * b) = a.band_first[b];
     }
     for (uint32_t i = tid * 16u; i < a.lut_bytes; i += nthr * 16u)
         *(uint4*)(lds + kLdsHdr + i) = *(const uint4*)((const uint8_t*)a.lut_img + i);
@@ -541,36 +532,29 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     // first lane group whose input a tile starting at stream symbol S needs (pixels: the packed converter starts at a
     // multiple of 4 triples = 2 groups)
     auto first_group = [](uint32_t S) -> uint32_t { return FE == FE_PIXELS ? ((S / 13u) & ~3u) / 2u : S / GS; };
-    uint32_t it = 0, n_st = 0;                                               // n_st: global stores issued since the last prefetch
     if constexpr (!IL) {                                                     // prologue: first tile's input
         if (blockIdx.x < a.n_tiles) stage_input<FE>(a, a.stage_off, first_group(blockIdx.x * TS), (blockIdx.x * TS + TS + GS - 1u) / GS, lane, wave, nwv);
     }
-    for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x, ++it) {
+    uint32_t younger = 0;                                                    // VMEM ops this wave issued after its last prefetch
+    for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const uint32_t S0 = tile * TS;
-        const uint32_t stage = a.stage_off + (IL ? 0u : (it & 1u) * a.stage_stride);
+        const uint32_t stage = a.stage_off;
         // ---------------- phase 1: input -> stream-ordered symbols in LDS ----------------
         if constexpr (!IL) {
-            barrier_input(n_st);                                              // this tile's input has landed; the other buffer is free
+            barrier_input(younger);                                           // this tile's input has landed, everyone left phase 2
             T3_STAMP(0);
-            const uint32_t nxt = tile + gridDim.x;
-#ifndef T3_PREFETCH_AFTER_P1
-            if (nxt < a.n_tiles)
-                stage_input<FE>(a, a.stage_off + ((it & 1u) ^ 1u) * a.stage_stride, first_group(nxt * TS), (nxt * TS + TS + GS - 1u) / GS, lane, wave, nwv);
-#endif
-            T3_STAMP(4);                                                      // (diagnostic) prefetch issue
 #ifndef T3_ABL_NO_P1
             if constexpr (FE == FE_PIXELS) convert_pixels_packed(a, stage, ((uint64_t)first_group(S0) * kGroupBytes) & ~15ull, S0, TS, lane, wave, nwv);
             else convert_groups<FE, false>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, tid, nthr);
 #endif
             T3_STAMP(5);                                                      // (diagnostic) this wave's conversion
-#ifdef T3_PREFETCH_AFTER_P1
-            if (nxt < a.n_tiles)
-                stage_input<FE>(a, a.stage_off + ((it & 1u) ^ 1u) * a.stage_stride, first_group(nxt * TS), (nxt * TS + TS + GS - 1u) / GS, lane, wave, nwv);
-#endif
-            barrier_lds();
+            barrier_lds();                                                    // symbols complete; the stage buffer is free again
             T3_STAMP(1);
+            const uint32_t nxt = tile + gridDim.x;                            // next tile's input streams in under phase 2
+            if (nxt < a.n_tiles) stage_input<FE>(a, stage, first_group(nxt * TS), (nxt * TS + TS + GS - 1u) / GS, lane, wave, nwv);
+            T3_STAMP(4);
         } else {
-            __syncthreads();                                                  // previous tile's copy-out has read the staging region
+            __syncthreads();                                                  // everyone left phase 2 of the previous tile
             for (uint32_t i = tid * 16u; i < TS; i += nthr * 16u) *(uint4*)(lds + a.sym_off + i) = make_uint4(0, 0, 0, 0);
             uint32_t u_lo = S0, u_hi = S0;                                   // pre-interleave symbols this tile needs: whole row segments
             const uint32_t hi = min(S0 + TS, a.n_sym);
@@ -588,57 +572,38 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             }
         }
 
-        // ---------------- phase 2: one lane = one RS block; a wave stays inside one band ----------------
+        // ---------------- phase 2: one lane = one RS block; a wave stays inside one band; stores go straight to HBM ----------------
+        younger = 0;
 #ifndef T3_ABL_NO_P2
-        if (wave < a.n_waves) {
-            const uint32_t b = wave_role(wave, 0), m = wave_role(wave, 1) + lane, nbt = band_row(b).nbt;
-            if constexpr (RSEL != 0) phase2_band<RSEL, true>(a, stage, tile, b, m, nbt, lane);
-            else switch (band_row(b).k) {
-                case 24: phase2_band<2, false>(a, stage, tile, b, m, nbt, lane); break;
-                case 22: phase2_band<4, false>(a, stage, tile, b, m, nbt, lane); break;
-                case 20: phase2_band<6, false>(a, stage, tile, b, m, nbt, lane); break;
-                default: phase2_band<8, false>(a, stage, tile, b, m, nbt, lane); break;
+        {
+            const uint32_t item = tid;                                        // one lane = one block, dealt linearly across the bands
+            bool did = false;
+            if constexpr (RSEL != 0) {
+                const uint32_t b = fdiv(item, a.div_nb), m = item - b * a.nb_uniform;
+                if (item < a.n_items) did = phase2_band<RSEL, true>(a, tile, b, m, a.nb_uniform);
+            } else if (item < a.n_items) {
+                uint32_t b = 0;
+#pragma unroll
+                for (uint32_t q = 1; q < 9; ++q) if (item >= band_first(q)) b = q;
+                const uint32_t m = item - band_first(b), nbt = band_row(b).nbt;
+                switch (band_row(b).k) {                                         // lanes of one wave may sit in two bands (mixed k: divergent)
+                    case 24: did = phase2_band<2, false>(a, tile, b, m, nbt); break;
+                    case 22: did = phase2_band<4, false>(a, tile, b, m, nbt); break;
+                    case 20: did = phase2_band<6, false>(a, tile, b, m, nbt); break;
+                    default: did = phase2_band<8, false>(a, tile, b, m, nbt); break;
+                }
             }
+            // single-k kernels: a wave with any valid block issues exactly kP2Stores store instructions after the prefetch
+            // (otherwise none: younger = 0 over-waits, which is safe); the mixed kernel does not count
+            if (RSEL != 0 && __builtin_amdgcn_ballot_w64(did) != 0) younger = kP2Stores;
         }
 #endif
-        // When every band is produced by exactly one wave (wave w <-> band w), the run a wave copies out in phase 3 is the
-        // run it has just written itself: LDS operations of one wave complete in order, so no workgroup barrier is needed.
-        if (a.p3_private) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else barrier_lds();
         T3_STAMP(2);
-
-        // ---------------- phase 3: coalesced copy-out, one band run per wave ----------------
-#ifndef T3_ABL_NO_P3
-        n_st = 0;
-        for (uint32_t b = wave; b < 9; b += nwv) {
-            const BandRow r = band_row(b);
-            const uint32_t nbt = r.nbt;
-            const uint64_t first_blk = (uint64_t)tile * nbt;
-            if (first_blk >= r.blocks) continue;
-            const uint32_t nvalid = (uint32_t)min((uint64_t)nbt, (uint64_t)r.blocks - first_blk);
-            const uint32_t Rb = 26u * nvalid;
-            uint8_t* g = a.body_out + r.body_off + 26ull * first_blk;
-            const uint32_t shift = (uint32_t)(uintptr_t)g & 15u;
-            const uint32_t src = stage + r.out_off + shift;
-            // wave-uniform counts in SGPRs: the stores below sit behind scalar branches, so n_st is exactly the number of
-            // store instructions this wave issues after its LDS-DMA prefetch (the top-of-tile wait is vmcnt(n_st))
-            const uint32_t head = __builtin_amdgcn_readfirstlane(min(Rb, (16u - shift) & 15u));
-            const uint32_t nmain = __builtin_amdgcn_readfirstlane((Rb - head) >> 4);
-            if (head) { if (2u * lane < head) *(uint16_t*)(g + 2u * lane) = *(const uint16_t*)(lds + src + 2u * lane); ++n_st; }
-            for (uint32_t i0 = 0; i0 < nmain; i0 += 64u) {
-                const uint32_t i = i0 + lane;
-                if (i < nmain) *(uint4*)(g + head + 16u * i) = *(const uint4*)(lds + src + head + 16u * i);
-                ++n_st;
-            }
-            const uint32_t done = head + 16u * nmain, tail = Rb - done;
-            if (tail) { if (2u * lane < tail) *(uint16_t*)(g + done + 2u * lane) = *(const uint16_t*)(lds + src + done + 2u * lane); ++n_st; }
-        }
-#endif
-        T3_STAMP(3);
     }
 #ifdef T3_STAMPS
     if (tid == 0 && a.dbg) {
         uint64_t* d = a.dbg + 8ull * blockIdx.x;
-        d[0] = st_acc[0]; d[1] = st_acc[1]; d[2] = st_acc[2]; d[3] = st_acc[3];
+        d[0] = st_acc[0]; d[1] = st_acc[1]; d[2] = st_acc[2]; d[3] = st_rt0;
         d[4] = __builtin_amdgcn_s_memtime() - st_t0; d[5] = __builtin_amdgcn_s_memrealtime() - st_rt0; d[6] = st_acc[4]; d[7] = st_acc[5];
     }
 #endif
