@@ -20,7 +20,7 @@ using namespace t3;
 
 namespace {
 
-struct LutImage { uint32_t* d_img = nullptr; uint32_t bytes = 0; uint32_t k_off[4] = {0, 0, 0, 0}; };
+struct LutImage { uint32_t* d_img = nullptr; uint32_t bytes = 0; uint32_t k_off[4] = {0, 0, 0, 0}; uint32_t* d_afrag = nullptr; };
 
 struct Ctx {
     int dev = -1; bool ready = false; int n_cu = 256;
@@ -29,6 +29,7 @@ struct Ctx {
     uint8_t* d_P[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     std::map<uint32_t, LutImage> luts;                  // key = kmask | mode << 8
     void* buf[4] = {nullptr, nullptr, nullptr, nullptr}; size_t cap[4] = {0, 0, 0, 0};   // grow-only device scratch
+    uint32_t* d_ctr = nullptr; std::map<hipStream_t, uint32_t> ctr_slot;   // tile-ticket counters, one pair per stream in use
     uint32_t* d_flag = nullptr;                         // failure counter for the synchronous decode entry points
     std::string hip_err;
     std::mutex mu;
@@ -72,6 +73,21 @@ int get_lut(uint32_t kmask, int mode, const LutImage** out) {
     return T3_OK;
 }
 
+// tables of the matrix-core encoder for one k (single-k launches)
+int get_mfma_lut(int k, int mode, const LutImage** out) {
+    const uint32_t key = 1u << k_index(k) | (uint32_t)mode << 8 | 1u << 16;
+    auto it = g.luts.find(key);
+    if (it == g.luts.end()) {
+        LutImage L; std::vector<uint32_t> afrag, img; build_mfma_encode(k, mode, afrag, img);
+        L.bytes = (uint32_t)img.size() * 4u;
+        HIPCHK(hipMalloc((void**)&L.d_img, L.bytes)); HIPCHK(hipMemcpy(L.d_img, img.data(), L.bytes, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&L.d_afrag, afrag.size() * 4)); HIPCHK(hipMemcpy(L.d_afrag, afrag.data(), afrag.size() * 4, hipMemcpyHostToDevice));
+        it = g.luts.emplace(key, L).first;
+    }
+    *out = &it->second;
+    return T3_OK;
+}
+
 DevDiv to_dev(FastDiv f) { return DevDiv{f.mul, f.sh, f.d}; }
 uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
 uint64_t gcd64(uint64_t a, uint64_t b) { while (b) { uint64_t t = a % b; a = b; b = t; } return a; }
@@ -81,7 +97,23 @@ uint64_t gcd64(uint64_t a, uint64_t b) { while (b) { uint64_t t = a % b; a = b; 
 // ------------------------------------------------------------------------------------------------
 struct EncLaunch { EncArgs a; uint32_t block; int rsel; };   // rsel = 26-k when all bands of the launch share k, else 0
 
-bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, int fe, const LutImage& lut, EncLaunch& out) {
+// Phase 1 (pixels) gives a lane two pixel triples of one parity, 4 triples apart per lane: waves per parity that cover the
+// worst-placed tile of TS symbols (tile starts cycle through S0 mod 52)
+uint32_t p1_waves_per_parity(uint32_t TS) {
+    uint32_t worst = 0;
+    for (uint32_t t = 0; t < 52; ++t) {
+        const uint64_t S0 = (uint64_t)t * TS;
+        const uint64_t t_base = (S0 / 13) & ~3ull, t_end = (S0 + TS + 12) / 13;
+        worst = std::max<uint32_t>(worst, (uint32_t)((t_end - t_base + 3) / 4));
+    }
+    return (worst + 63) / 64;
+}
+
+// mfma_sets != 0: the matrix-core layout (single k, all nine bands): wave = band, tile = 32 * mfma_sets blocks per band,
+// nine per-wave output images behind the stage buffer; fails when that does not fit `mfma_budget` bytes of LDS
+constexpr uint32_t kOutStride = 864;   // must match t3_kernels.hip
+bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, int fe, const LutImage& lut, EncLaunch& out,
+                    uint32_t mfma_sets = 0, uint32_t mfma_budget = 0) {
     EncArgs& a = out.a; memset(&a, 0, sizeof a);
     const uint32_t GS = fe == FE_PIXELS ? kGroupSyms : kGroupSymsW, GB = fe == FE_PIXELS ? kGroupBytes : kGroupBytesW;
     uint64_t Lk = 2;
@@ -89,6 +121,13 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     uint32_t lut_bytes = lut.bytes;
     // pick q (even): tile = 9*Lk*q stream symbols; band b then owns Lk*q/k_b blocks = that/2 lane pairs
     double best_score = -1; uint32_t best_q = 0;
+    if (mfma_sets) {
+        const uint64_t Lq = Lk * 32u * mfma_sets / (Lk / L.band_k[0]);          // Lk = lcm(2, k) = k for the even k's in use
+        const uint32_t groups = (uint32_t)(9 * Lq / GS) + 6, stage = groups * GB + 1024 + 32;
+        const uint32_t total = kLdsHdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq)) + 16 + round16(stage) + 9 * kOutStride;
+        if (Lq % Lk != 0 || total > mfma_budget || (fe == FE_PIXELS && 2 * p1_waves_per_parity((uint32_t)(9 * Lq)) > 9)) return false;
+        best_q = (uint32_t)(Lq / Lk);
+    }
     for (int pass = 0; pass < 2 && !best_q; ++pass) {
         const uint32_t budget = pass == 0 ? 53u * 1024u : 160u * 1024u;     // <= 53 KiB: three workgroups per CU
         for (uint32_t q = 2; q <= 4096; q += 2) {
@@ -101,11 +140,14 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
             waves = (blocks_total + 63) / 64;                          // lanes are dealt to blocks linearly across bands
             if (waves > (pass == 0 ? 8u : (uint32_t)kMaxWaves)) break;   // pass 0: 512-thread workgroups, three per CU
             const uint32_t groups = (uint32_t)(9 * Lq / GS) + 6, stage = groups * GB + 1024 + 32;   // +1 KiB: LDS-DMA pieces are whole
-            const uint32_t total = kLdsHdr + round16(lut_bytes) + round16((uint32_t)(9 * Lq)) + 16 + round16(stage);
+            const uint32_t total = kLdsHdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq)) + 16 + round16(stage);
             (void)outb;
             if (total > budget) break;
-            const double util = (double)blocks_total / (64.0 * waves);
-            const double score = util + 1e-7 * (double)Lq;          // utilisation first, then the larger tile
+            // wave-instructions per stream symbol: phase 2 costs ~180 per wave, phase 1 (pixels) ~120 per wave-iteration
+            const uint32_t wpp = p1_waves_per_parity((uint32_t)(9 * Lq));
+            if (fe == FE_PIXELS && 2 * wpp > std::max(waves, 4u)) continue;
+            const double cost = (180.0 * waves + (fe == FE_PIXELS ? 240.0 * wpp : 180.0 * waves)) / (double)(9 * Lq);
+            const double score = 1.0 / cost + 1e-9 * (double)Lq;
             if (score > best_score) { best_score = score; best_q = q; }
         }
     }
@@ -113,7 +155,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     const uint32_t Lq = (uint32_t)(Lk * best_q);
     a.Lq = Lq; a.lut_bytes = round16(lut_bytes);
     uint32_t off = kLdsHdr + a.lut_bytes;
-    a.sym_off = off; off += round16(9 * Lq) + 16;
+    off += kSymFront; a.sym_off = off; off += round16(9 * Lq) + 16;   // slack either side: phase 1 writes whole pixel triples
     a.stage_off = off;
     a.stage_groups = 9 * Lq / GS + 6;
     uint32_t outb = 0, nw = 0, n_tiles = 0;
@@ -131,16 +173,19 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     { uint32_t acc = 0; for (int b = 0; b < 9; ++b) { a.band_first[b] = acc; acc += a.band_nb_tile[b]; } a.band_first[9] = acc; }
     a.stage_stride = round16(a.stage_groups * GB + 1024 + 32);
     a.lds_bytes = a.stage_off + a.stage_stride;
+    if (mfma_sets) { a.p2_sets = mfma_sets; a.out_off = a.lds_bytes; a.lds_bytes += 9 * kOutStride; }
     a.n_sym = (uint32_t)L.n_sym;
     const ScrCycle sc = scrambler_cycle(cfg.seed_a, cfg.seed_b, cfg.seed_s0);
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
+    mfma_scrambler_table(L.band_k[0], sc, a.scr);
     a.il_on = L.interleave2d;
     if (a.il_on) {
         const uint64_t A = (uint64_t)cfg.tile_w * cfg.tile_h;
         a.il_w = cfg.tile_w; a.il_A = (uint32_t)std::min<uint64_t>(A, std::max<uint64_t>(L.n_sym, 1));
         a.div_A = to_dev(fastdiv(a.il_A)); a.div_w = to_dev(fastdiv(a.il_w));
     }
-    out.block = 64u * std::max<uint32_t>((nw + 63) / 64, 4u);
+    out.block = mfma_sets ? 576u : 64u * std::max<uint32_t>((nw + 63) / 64, 4u);
+    a.p1_wpp = p1_waves_per_parity(9 * Lq);
     out.rsel = 0;
     { int k0 = 0; bool same = true; for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) { if (!k0) k0 = L.band_k[b]; else if (k0 != L.band_k[b]) same = false; } if (same && k0 && band_mask == 0x1FF) out.rsel = 26 - k0; }
     a.nb_uniform = out.rsel ? a.band_nb_tile[0] : 0u; a.div_nb = to_dev(fastdiv(a.nb_uniform ? a.nb_uniform : 1u));
@@ -163,17 +208,36 @@ int launch_fn(const void* fn, const EncLaunch& e, hipStream_t s) {
     const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(e.a.n_tiles, (uint32_t)(g.n_cu * per_cu)));
 #ifdef T3_STAMPS
     static uint64_t* d_dbg = nullptr; static int calls = 0;
-    if (!d_dbg) HIPCHK(hipMalloc((void**)&d_dbg, 8 * 8 * 4096));
-    HIPCHK(hipMemsetAsync(d_dbg, 0, 8 * 8 * 4096, s));
+    if (!d_dbg) HIPCHK(hipMalloc((void**)&d_dbg, 16 * 8 * 4096));
+    HIPCHK(hipMemsetAsync(d_dbg, 0, 16 * 8 * 4096, s));
     const_cast<EncLaunch&>(e).a.dbg = d_dbg;
 #endif
+    {   // dynamic tile tickets: a zeroed counter pair per stream (launches on one stream are ordered; the kernel re-zeroes it)
+        static const bool off = getenv("T3HIP_STATIC_TILES") != nullptr;      // measurement knob
+        constexpr uint32_t kSlots = 64, kSlotWords = 64 * 9;                  // 8 class counters + 1 done counter, 256 B apart
+        if (!g.d_ctr) { HIPCHK(hipMalloc((void**)&g.d_ctr, kSlots * kSlotWords * 4)); HIPCHK(hipMemset(g.d_ctr, 0, kSlots * kSlotWords * 4)); }
+        auto sl = g.ctr_slot.find(s);
+        if (sl == g.ctr_slot.end() && g.ctr_slot.size() < kSlots) sl = g.ctr_slot.emplace(s, (uint32_t)g.ctr_slot.size()).first;
+        const_cast<EncLaunch&>(e).a.tile_ctr = (off || sl == g.ctr_slot.end()) ? nullptr : g.d_ctr + kSlotWords * sl->second;
+        const_cast<EncLaunch&>(e).a.n_classes = std::min<uint32_t>(8u, grid);
+    }
     void* args[] = {(void*)&e.a};
     HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(e.block), args, e.a.lds_bytes, s));
 #ifdef T3_STAMPS
     if (++calls == 8) {                                     // one report, after warm-up
-        std::vector<uint64_t> h(8 * grid);
+        std::vector<uint64_t> h16(16 * grid), h(8 * grid);
         HIPCHK(hipStreamSynchronize(s));
-        HIPCHK(hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h16.data(), d_dbg, h16.size() * 8, hipMemcpyDeviceToHost));
+        for (uint32_t w = 0; w < grid; ++w) for (int i = 0; i < 8; ++i) h[8 * w + i] = h16[16 * w + i];
+        { std::map<uint32_t, std::vector<uint32_t>> per_cu; double xl[8] = {0}; int xn[8] = {0};
+          for (uint32_t w = 0; w < grid; ++w) { const uint32_t hw = (uint32_t)h16[16 * w + 8], xcc = (uint32_t)h16[16 * w + 9] & 15u;
+              per_cu[xcc << 16 | (hw >> 8 & 0xFFu)].push_back((uint32_t)h[8 * w + 5]); xl[xcc & 7] += (double)h[8 * w + 5] * 0.01; ++xn[xcc & 7]; }
+          int hist[8] = {0}; for (auto& kv : per_cu) ++hist[std::min<size_t>(kv.second.size(), 7)];
+          fprintf(stderr, "[t3 stamps]   CUs seen=%zu  CUs holding n WGs: 1:%d 2:%d 3:%d 4:%d 5:%d 6+:%d\n", per_cu.size(), hist[1], hist[2], hist[3], hist[4], hist[5], hist[6] + hist[7]);
+          fprintf(stderr, "[t3 stamps]   mean WG lifetime (us) per XCC:"); for (int x = 0; x < 8; ++x) fprintf(stderr, " %d:%.1f(n=%d)", x, xn[x] ? xl[x] / xn[x] : 0.0, xn[x]); fprintf(stderr, "\n");
+          double ln[8] = {0}; int cn[8] = {0}; for (auto& kv : per_cu) { const size_t n = std::min<size_t>(kv.second.size(), 7); for (uint32_t v : kv.second) { ln[n] += v * 0.01; ++cn[n]; } }
+          fprintf(stderr, "[t3 stamps]   mean WG lifetime (us) by WGs on its CU:"); for (int n = 1; n < 8; ++n) if (cn[n]) fprintf(stderr, " %d:%.1f", n, ln[n] / cn[n]); fprintf(stderr, "\n");
+          fprintf(stderr, "[t3 stamps]   hw_id samples: %08x %08x %08x %08x\n", (unsigned)h16[8], (unsigned)h16[16 + 8], (unsigned)h16[32 + 8], (unsigned)h16[16 * 100 + 8]); }
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (uint32_t w = 0; w < grid; ++w) for (int i = 0; i < 8; ++i) acc[i] += (double)h[8 * w + i];
         fprintf(stderr, "[t3 stamps] grid=%u tiles=%u  mean cycles/WG: stage=%.0f p1=%.0f p2=%.0f p3=%.0f total=%.0f  clock=%.3f GHz\n", grid, e.a.n_tiles,
@@ -189,7 +253,7 @@ int launch_fn(const void* fn, const EncLaunch& e, hipStream_t s) {
 }
 template <int FE, bool IL> int launch_enc2(const EncLaunch& e, hipStream_t s) {
     const void* fn = (const void*)encode_kernel_mixed<FE, IL>;
-    if (e.block <= 640) switch (e.rsel) {                      // single-k launches use the leaner 640-thread kernels
+    if (e.a.afrag) switch (e.rsel) {                           // single-k launches: matrix-core kernels (<= 640 threads)
         case 2: fn = (const void*)encode_kernel_k<FE, IL, 2>; break;
         case 4: fn = (const void*)encode_kernel_k<FE, IL, 4>; break;
         case 6: fn = (const void*)encode_kernel_k<FE, IL, 6>; break;
@@ -225,17 +289,27 @@ int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, vo
     // group bands into launches: all together when the lcm of their k's keeps the tile small, else one launch per k
     uint32_t kmask = 0; for (int b = 0; b < 9; ++b) kmask |= 1u << k_index(L.band_k[b]);
     std::vector<uint32_t> groups;
+    const bool single_k = (kmask & (kmask - 1)) == 0;                    // one k for all nine bands: matrix-core kernels
     {
         const LutImage* lut; rc = get_lut(kmask, cfg->mode, &lut); if (rc) return rc;
         EncLaunch e;
-        if (plan_enc_group(L, *cfg, 0x1FF, fe, *lut, e)) groups.push_back(0x1FF);
+        if (single_k || plan_enc_group(L, *cfg, 0x1FF, fe, *lut, e)) groups.push_back(0x1FF);
         else for (int i = 0; i < 4; ++i) if (kmask >> i & 1) { uint32_t m = 0; for (int b = 0; b < 9; ++b) if (k_index(L.band_k[b]) == i) m |= 1u << b; groups.push_back(m); }
     }
     bool first = true;
     for (uint32_t m : groups) {
         uint32_t km = 0; for (int b = 0; b < 9; ++b) if (m >> b & 1) km |= 1u << k_index(L.band_k[b]);
-        const LutImage* lut; rc = get_lut(km, cfg->mode, &lut); if (rc) return rc;
-        EncLaunch e; if (!plan_enc_group(L, *cfg, m, fe, *lut, e)) return T3_E_ARG;
+        bool mfma = single_k && m == 0x1FF;
+        const LutImage* lut; EncLaunch e;
+        if (mfma) {                                                      // matrix-core kernel: 64 or 32 blocks per band and tile
+            rc = get_mfma_lut(L.band_k[0], cfg->mode, &lut); if (rc) return rc;
+            mfma = plan_enc_group(L, *cfg, m, fe, *lut, e) && e.rsel && e.block <= 512;   // the tile must fit eight waves
+        }
+        if (!mfma) {
+            rc = get_lut(km, cfg->mode, &lut); if (rc) return rc;
+            if (!plan_enc_group(L, *cfg, m, fe, *lut, e)) return T3_E_ARG;
+        }
+        e.a.afrag = mfma ? lut->d_afrag : nullptr;
         e.a.in = (const uint8_t*)d_in; e.a.n_units = n_units; e.a.n_units_pad = fe == FE_PIXELS ? 2 * n_raw : n_units;
         e.a.body_out = body_out; e.a.frame_out = first ? frame_out : nullptr; e.a.lut_img = lut->d_img;
         e.a.hdr_syms = hs; e.a.pad_bytes = pad; e.a.out_syms = L.out_syms; memcpy(e.a.hdr, hdr, sizeof hdr);

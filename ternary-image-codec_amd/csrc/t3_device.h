@@ -9,6 +9,7 @@ enum FrontEnd : int { FE_PIXELS = 0, FE_WORDS = 1 };
 
 constexpr int kMaxWaves = 16;            // 1024-thread workgroup
 constexpr int kLdsHdr = 512;            // LDS header: 9 band rows (32 B) + wave roles
+constexpr int kSymFront = 64;           // slack in front of the LDS symbol buffer (phase 1 writes whole pixel triples)
 constexpr int kGroupSyms = 26;           // symbols one phase-1 lane produces from pixels: 6 px = 36 B -> 26 symbols
 constexpr int kGroupBytes = 36;
 constexpr int kGroupSymsW = 52;          // from raw words: 6 words = 54 B -> 52 symbols
@@ -21,7 +22,8 @@ struct EncArgs {
     const uint8_t* in;              // pixels (6 B each) or raw Word27 (9 B each), 16-B aligned
     uint8_t*  body_out;             // address of body symbol 0 (final stream + header, or scratch when a beacon pass follows)
     uint8_t*  frame_out;            // final stream base; header/pad written by tile 0 when non-null
-    const uint32_t* lut_img;        // concatenated LUT images of the k's in use (global)
+    const uint32_t* lut_img;        // LDS table image: concatenated LUTs of the k's in use (mixed k) or the T/M tables (single k)
+    const uint32_t* afrag;          // single-k launches: matrix operand of the parity MFMA, 3 steps x 64 lanes x 4 dwords
     uint32_t  lut_bytes;            // total bytes to stage into LDS (multiple of 16)
     uint64_t  n_units;              // real pixels / words in `in`
     uint64_t  n_units_pad;          // pixels: 2*n_words (odd count pads one zero pixel, OLD:730); words: = n_units
@@ -43,11 +45,16 @@ struct EncArgs {
     uint32_t  stage_stride;         // bytes between the two input stage buffers (out staging aliases the current one)
     uint32_t  stage_groups;         // capacity of one input stage buffer, in lane groups
     uint32_t  cyc24; uint32_t pre0, pre1;      // scrambler: 6-periodic tail as 2-bit fields (x2), two pre-period states
+    uint32_t  scr[12];              // single-k launches: scrambler dwords of the parity symbols per phase (mfma_scrambler_table)
     uint32_t  il_on, il_w, il_A;    // 2-D boustrophedon: row width, chunk area (clamped to n_sym)
     DevDiv    div_A, div_w;
     uint32_t  hdr_syms; uint32_t pad_bytes;    // header symbols; zero bytes after the last symbol (OLD:1164-1167)
     uint64_t  out_syms;
     uint8_t   hdr[96];
+    uint32_t* tile_ctr;             // ticket counters [64 * class], then workgroups-finished at [64 * n_classes] (last one re-zeroes); null = static striding
+    uint32_t  n_classes;            // ticket classes (<= grid)
+    uint32_t  p1_wpp;               // phase 1 (pixels): waves per triple parity that cover a tile
+    uint32_t  p2_sets, out_off;     // single-k launches: sets of 32 blocks per wave (= band) and tile; LDS offset of the per-wave output images
     uint64_t* dbg;                  // diagnostic stamp builds only (T3_STAMPS); null in the product
 };
 

@@ -164,6 +164,48 @@ void build_encode_lut(int k, int mode, std::vector<uint32_t>& image) {
     }
 }
 
+void build_mfma_encode(int k, int mode, std::vector<uint32_t>& afrag, std::vector<uint32_t>& lds_img) {
+    const Field& F = field();
+    const int r = 26 - k, H = r / 2;
+    std::vector<uint8_t> P((size_t)k * r); rs_parity_matrix(k, mode, P.data());
+    afrag.assign(3 * 64 * 4, 0u);
+    for (int s = 0; s < 3; ++s) for (int l = 0; l < 64; ++l) for (int d = 0; d < 4; ++d) {
+        const int m = l & 31, kh = l >> 5, hh = (m >> 2) & 1, i = (m & 3) + 4 * (m >> 3);
+        const int p = 8 * s + 4 * kh + d;
+        if (i >= 3 * H) continue;
+        const int j = hh * H + i / 3, t = i % 3;
+        uint32_t dw = 0;
+        if (p < k) {
+            for (int tt = 0; tt < 3; ++tt) {
+                const int e = tt == 0 ? 1 : tt == 1 ? 3 : 9;                  // the symbol whose only non-zero trit is tt
+                const int c = F.t.mul[e * 27 + P[p * r + j]];
+                const int tr[3] = {c % 3, (c / 3) % 3, c / 9};
+                dw |= (uint32_t)(tr[t] == 2 ? 0xFFu : (uint32_t)tr[t]) << (8 * tt);   // signed: 2 == -1
+            }
+        } else if (r >= 4 && (p == mfma_scr_pos(k) || p == mfma_scr_pos(k) + 1)) {
+            for (int bb = 0; bb < 4; ++bb) if (4 * (p - mfma_scr_pos(k)) + bb == j) dw |= 1u << (8 * bb);
+        }
+        afrag[(size_t)(s * 64 + l) * 4 + d] = dw;
+    }
+    lds_img.assign(kMfmaLdsBytes / 4, 0u);
+    auto sb = [](int t) { return (uint32_t)(t == 2 ? 0xFF : t); };
+    for (int v = 0; v < 3; ++v) for (int d = 0; d < 27; ++d) {
+        const uint32_t dw = sb(d % 3) | sb((d / 3) % 3) << 8 | sb(d / 9) << 16 | (uint32_t)add13((uint8_t)d, v) << 24;
+        for (int c = 0; c < 32; ++c) lds_img[(size_t)v * kMfmaTState / 4 + (size_t)d * 32 + c] = dw;
+    }
+    uint8_t* mt = (uint8_t*)lds_img.data() + kMfmaModOff;
+    for (int t = 0; t < 3; ++t) for (int x = 0; x < 128; ++x) mt[128 * t + x] = (uint8_t)((((x - 64) % 3 + 3) % 3) * (t == 0 ? 1 : t == 1 ? 3 : 9));
+}
+
+void mfma_scrambler_table(int k, const ScrCycle& sc, uint32_t out[12]) {
+    const int r = 26 - k;
+    for (int c = 0; c < 6; ++c) {
+        uint32_t dw[2] = {0, 0};
+        for (int j = 0; j < r && j < 8; ++j) dw[j / 4] |= (uint32_t)sc.cyc[(c + j) % 6] << (8 * (j % 4));
+        out[2 * c] = dw[0]; out[2 * c + 1] = dw[1];
+    }
+}
+
 int syndrome_lut_slab(int k) { return 26 - k == 8 ? 768 : 512; }
 void build_syndrome_lut(int k, std::vector<uint32_t>& image) {
     const Field& F = field(); RsView v = rs_view(F.t);

@@ -50,6 +50,23 @@ LutGeom lut_geom(int k);
 //   [A: 27 x {dw0,dw1}] [B (r=8 only): 27 x {dw2,dw3}] [V_0][V_1][V_2], V_s: 27 x {dw2, dw3|img<<24} (r=6) or {dwv|img<<24, 0}.
 void build_encode_lut(int k, int mode, std::vector<uint32_t>& image);
 
+// Tables of the matrix-core encoder (single-k launches).  Parity is a GF(3)-linear map of the data trits:
+// per block an 3r x 3k matrix-vector product mod 3, done by v_mfma_i32_32x32x32_i8 for 32 blocks at a time.
+// Trits travel as signed bytes (2 == -1), so a trit sum lies in [-60, 60]; the accumulators start at 64.
+//   afrag : A operand (the matrix), 3 K-steps x 64 lanes x 4 dwords, in the instruction's lane order: lane l = (row m = l&31,
+//           K-half kh = l>>5), dword d of step s = data position p = 8s + 4kh + d, byte tt = coefficient of trit tt of that
+//           symbol (byte 3 = 0).  Row m holds accumulator register i = (m&3) + 4(m>>3) of lane half hh = (m>>2)&1 (the C/D
+//           layout row = (i&3) + 8(i>>2) + 4hh), which is trit i%3 of parity symbol hh*r/2 + i/3 (rows with i >= 3r/2 are zero).
+//           r >= 4: the unused positions mfma_scr_pos(k), +1 carry the scrambler states of the parity symbols, one per byte
+//           (coefficient 1 on the three trit rows of parity symbol 4 (p - scr_pos) + byte).
+//   lds   : [T: 3 scrambler states x 27 symbols x 32 bank copies, dword = trit0 | trit1<<8 | trit2<<16 | scrambled symbol<<24,
+//           at v * 4096 + (d * 32 + bank) * 4: every lane reads its own bank, no conflicts]
+//           [M_t, t<3: 128 bytes, M_t[x] = 3^t ((x - 64) mod 3)]: the mod-3 fold of a biased trit sum, 32 dwords = 32 banks
+constexpr int kMfmaTState = 4096, kMfmaTBytes = 3 * kMfmaTState, kMfmaModOff = kMfmaTBytes, kMfmaLdsBytes = kMfmaTBytes + 3 * 128;
+inline int mfma_scr_pos(int k) { return k == 22 ? 22 : 20; }     // k = 24 has no free position (states added after the MFMA)
+void build_mfma_encode(int k, int mode, std::vector<uint32_t>& afrag, std::vector<uint32_t>& lds_img);
+
+
 // Syndrome LUT for the fused decoder: position i (0..25), symbol c -> c * alpha^{(j+1) i} for j < r as 6-bit SWAR trit
 // fields, same dword layout as the encode LUT ("main" parities -> syndromes 0..4 plane-major, extras after), two 8-byte
 // tables per position (A: {dw0,dw1} at +0, B: {dw2,dw3} at +256; r=8 adds C: {dw4,0} at +512). 26 * slab bytes.
@@ -65,6 +82,8 @@ struct ScrCycle {
 };
 ScrCycle scrambler_cycle(uint32_t a, uint32_t b, uint32_t s0);
 ScrCycle scrambler_cycle_from_next(const uint8_t next[3], uint32_t s0);
+// the scrambler dwords of those positions for each phase c = (phase of the block's first parity symbol): out[2c], out[2c+1]
+void mfma_scrambler_table(int k, const ScrCycle& sc, uint32_t out[12]);
 
 // ---- header (OLD:155-380) ---------------------------------------------------------------------------
 void crc12(const uint8_t* trits, int n, uint8_t out[12]);

@@ -16,6 +16,14 @@
 namespace t3 {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+// LDS access by absolute byte address.  The kernels own the whole LDS allocation (no static __shared__), so the dynamic
+// array starts at address 0; going through `lds + x` instead makes the compiler add that (link-time) zero to every address.
+#define T3_LDS_PTR(T, a) ((const __attribute__((address_space(3))) T*)(uintptr_t)(a))
+#define T3_LDS_WPTR(T, a) ((__attribute__((address_space(3))) T*)(uintptr_t)(a))
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t lds_u8(uint32_t a)  { return *T3_LDS_PTR(uint8_t, a); }
+__device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *T3_LDS_PTR(uint32_t, a); }
 
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, const DevDiv& d) { return d.d <= 1 ? n : (__umulhi(n, d.mul) >> d.sh); }
 
@@ -273,7 +281,119 @@ __device__ __forceinline__ bool phase2_band(const EncArgs& a, uint32_t tile, uin
     *(uint16_t*)(G + (al ? 24 : 0)) = (uint16_t)(al ? o.w[6] : o.w[0]);                // and the remaining short
     return true;
 }
-constexpr uint32_t kP2Stores = 7;   // global store instructions a wave issues in phase 2 (counted vmcnt at the tile top)
+
+// ---------------------------------------------------------------------------------------------------------
+// Phase 2 on the matrix cores (single-k launches).  RS parity is GF(3)-linear in the data trits: per block a (3r x 3k)
+// matrix-vector product mod 3.  One v_mfma_i32_32x32x32_i8 chain (3 K-steps) does it for 32 blocks: the B operand is the
+// data, one dword per symbol = its three trits as bytes (byte 3 carries the scrambled symbol and meets a zero matrix
+// column), fetched from a 27-entry LDS table per scrambler state; lane (n, h) supplies positions 8s + 4h + d of block n in
+// K-step s.  The A operand (the matrix, host-built in the instruction's lane order) sits in 12 VGPRs.  The accumulators
+// come back as: lane (n, h) holds the three trit sums of parity symbols h r/2 .. h r/2 + r/2 - 1 of block n; adding the
+// scrambler state and folding mod 3 is three byte-table reads per symbol.  A wave does two sets of 32 blocks.
+// Output: lane (n, h) owns bytes [8s + 4h, +4) of the block for s = 0..2 (plus bytes 24, 25 for h = 1): three dword
+// stores at 2-byte alignment and one short.  Returns the number of global store instructions issued (wave-uniform).
+// ---------------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+struct __attribute__((packed, aligned(2))) U32a2 { uint32_t v; };
+struct __attribute__((packed, aligned(2))) U96a2 { uint32_t v[3]; };
+constexpr uint32_t kMfmaModOff = 3 * 4096, kMfmaScr = 336;     // must match t3_host.hpp; scrambler dwords sit in the LDS header
+
+template <int R>
+__device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t tile, uint32_t wave, uint32_t lane, const v4i (&Afr)[3]) {
+    constexpr uint32_t K = 26 - R, H = R / 2;
+    constexpr uint32_t TB = kLdsHdr, MB = kLdsHdr + kMfmaModOff;
+    const uint32_t n = lane & 31u, h = lane >> 5;
+    const uint32_t tb3 = __builtin_amdgcn_readfirstlane((tile * a.nb_uniform) % 3u);
+    uint32_t issued = 0;
+#pragma unroll
+    for (uint32_t set = 0; set < 2; ++set) {                                  // a wave does two sets of 32 blocks
+        const uint32_t item = wave * 64u + set * 32u + n;                     // blocks are dealt linearly across the bands
+        const uint32_t b = min(fdiv(item, a.div_nb), 8u), m = item - b * a.nb_uniform;
+        const BandRow r = band_row(b);
+        const uint32_t mg = tile * a.nb_uniform + m;
+        const bool valid = item < a.n_items && mg < r.blocks;
+        if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;               // wave-uniform
+        // scrambler phase of the block's first symbol: (boff6 + 2 (mg mod 3)) mod 6 (26 == 2 mod 6), without wide multiplies
+        uint32_t m3 = tb3 + m - 3u * ((m * 683u) >> 11); m3 -= m3 >= 3u ? 3u : 0u;   // m < 2048
+        uint32_t c0 = r.boff6 + 2u * m3; c0 -= c0 >= 6u ? 6u : 0u;
+        uint32_t c0h = c0 + 4u * h; c0h -= c0h >= 6u ? 6u : 0u;               // ... of this lane's first position 4h
+        const uint32_t cycs = a.cyc24 >> (2u * c0h);
+        uint32_t vb[6];                                                       // table base per position class: state (4 KiB apart), own bank copy
+#pragma unroll
+        for (uint32_t q = 0; q < 6; ++q) vb[q] = (((cycs >> (2u * q)) & 3u) << 12) | (TB + 4u * n);
+        const uint32_t sa = a.sym_off + b + 9u * K * m + 36u * h;
+        v4i Bv[3]; uint32_t W[3]; uint32_t dd0 = 0, dd1 = 0;
+#pragma unroll
+        for (uint32_t s = 0; s < 3; ++s) {
+            uint32_t x[4];
+#pragma unroll
+            for (uint32_t d = 0; d < 4; ++d) {
+                const uint32_t d4 = lds_u8(sa + 72u * s + 9u * d);            // positions >= k read neighbouring bytes: they meet zero matrix columns
+                if (s == 0 && d == 0) dd0 = d4;
+                if (s == 0 && d == 1) dd1 = d4;
+                x[d] = lds_u32((d4 << 5) + vb[(8u * s + d) % 6u]);
+                Bv[s][d] = (int)x[d];
+            }
+            const uint32_t t01 = __builtin_amdgcn_perm(x[1], x[0], 0x0c0c0703u), t23 = __builtin_amdgcn_perm(x[3], x[2], 0x07030c0cu);
+            W[s] = t01 | t23;                                                  // the four scrambled symbols
+        }
+        uint32_t c0K = c0 + (K % 6u); c0K -= c0K >= 6u ? 6u : 0u;             // scrambler phase of the first parity symbol
+        if constexpr (R >= 4) {     // the states of the parity symbols ride in unused positions of the upper half (see mfma_scr_pos)
+            const u32x2 sd = *T3_LDS_PTR(u32x2, kMfmaScr + 8u * c0K);
+            if constexpr (R == 4) Bv[2][2] = h ? (int)sd.x : Bv[2][2];
+            else { Bv[2][0] = h ? (int)sd.x : Bv[2][0]; Bv[2][1] = h ? (int)sd.y : Bv[2][1]; }
+        }
+        v16i acc = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64};   // bias: trit sums in [-60, 62] -> table index
+#ifndef T3_ABL_NO_MFMA
+#pragma unroll
+        for (uint32_t s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Afr[s], Bv[s], acc, 0, 0, 0);
+#else
+        acc[0] += Bv[0][0] & 1; acc[3] += Bv[1][1] & 1; acc[6] += Bv[2][2] & 1; acc[1] += (Bv[0][1] ^ Bv[0][2] ^ Bv[0][3] ^ Bv[1][0] ^ Bv[1][2] ^ Bv[1][3] ^ Bv[2][0] ^ Bv[2][1] ^ Bv[2][3]) & 1;
+#endif
+        // parity symbols of this lane: h H + jj; mod-3 fold and 3^t weight by byte tables (one bank per dword: conflict-free)
+        uint32_t Pown = 0;
+#pragma unroll
+        for (uint32_t jj = 0; jj < H; ++jj) {
+            uint32_t x0 = (uint32_t)acc[3 * jj], x1 = (uint32_t)acc[3 * jj + 1], x2 = (uint32_t)acc[3 * jj + 2];
+            if constexpr (R == 2) {                                              // k = 24: no free position, add the state here
+                const uint32_t st = (a.cyc24 >> (2u * (c0K + h))) & 3u;
+                x0 += st; x1 += st; x2 += st;
+            }
+            const uint32_t sym = lds_u8(MB + x0) + lds_u8(MB + 128u + x1) + lds_u8(MB + 256u + x2);
+            Pown |= sym << (8u * jj);
+        }
+        const uint32_t Plo = __builtin_amdgcn_permlane32_swap(Pown, Pown, false, false)[0];   // upper half: the h = 0 partner's parities
+        uint32_t W2 = W[2], tail;
+        if constexpr (R == 6)      { W2 = h ? ((Plo & 0x00FFFFFFu) | (Pown << 24)) : W2; tail = Pown >> 8; }
+        else if constexpr (R == 8) { W2 = h ? ((Plo >> 16) | (Pown << 16)) : ((W2 & 0xFFFFu) | (Pown << 16)); tail = Pown >> 16; }
+        else if constexpr (R == 4) { W2 = h ? ((W2 & 0xFFFFu) | (Plo << 16)) : W2; tail = Pown; }
+        else                       { tail = (Plo & 0xFFu) | (Pown << 8); }
+        uint32_t W0 = W[0];
+        if (r.body_off == 0 && mg == 0 && h == 0)               // body symbols 0 and 1 see the pre-period states (exact whatever the seed; OLD:81-87)
+            W0 = (W0 & 0xFFFF0000u) | add13(dd0 >> 2, a.pre0) | (add13(dd1 >> 2, a.pre1) << 8);
+        // Lane (n, h) holds bytes [8s + 4h, +4) of block n.  One half-wave exchange gives every lane 12 consecutive bytes
+        // (h = 0: bytes 0..11, h = 1: bytes 12..23 and the last two), so a set goes out in one 12-byte and one 2-byte store
+        // per lane instead of three scattered dwords: a quarter of the cache-line requests.
+        const auto sw = __builtin_amdgcn_permlane32_swap(W0, W2, false, false);   // upper half of W0 (bytes 4..7) <-> lower half of W2 (bytes 16..19)
+        const uint32_t Xa = sw[0], Xb = sw[1];                                    // h=0: Xa = bytes 0..3, Xb = 4..7;   h=1: Xa = 16..19, Xb = 20..23
+        const uint32_t S0 = h ? W[1] : Xa, S1 = h ? Xa : Xb, S2 = h ? Xb : W[1];   // h=0: 0..3, 4..7, 8..11;  h=1: 12..15, 16..19, 20..23
+#ifdef T3_ABL_NO_STORE
+        if (valid && a.n_tiles == 0xFFFFFFFFu) {
+#else
+        if (valid) {
+#endif
+            uint8_t* G = a.body_out + r.body_off + 26ull * mg + 12u * h;          // 2-byte aligned
+            ((U96a2*)G)->v[0] = S0; ((U96a2*)G)->v[1] = S1; ((U96a2*)G)->v[2] = S2;
+            if (h) *(uint16_t*)(G + 12) = (uint16_t)tail;                          // bytes 24, 25 of the block
+        }
+#ifndef T3_ABL_NO_STORE
+        issued += 2u;
+#endif
+    }
+    return issued;
+}
 
 // Stage the input bytes of lane groups [g_lo, g_hi) into the stage buffer at LDS offset `stage`: image byte x = input
 // byte b0 + x with b0 = 16-aligned start of group g_lo.  Whole 1-KiB pieces inside the real data go by LDS-DMA
@@ -312,7 +432,7 @@ __device__ __forceinline__ void stage_input(const EncArgs& a, uint32_t stage, ui
 }
 
 // Phase 1: lane groups [g_lo, g_hi) of the stage buffer -> stream-ordered symbols [S0, S0+TS) in LDS.
-template <int FE, bool IL>
+template <int FE, bool IL, int SH>     // SH: symbols are stored pre-scaled by 2^SH (the byte offset of their table entry)
 __device__ __forceinline__ void convert_groups(const EncArgs& a, uint32_t stage, uint32_t g_base, uint32_t g_lo, uint32_t g_hi,
                                                uint32_t S0, uint32_t TS, uint32_t tid, uint32_t nthr) {
     constexpr uint32_t GS = FE == FE_PIXELS ? kGroupSyms : kGroupSymsW, GB = FE == FE_PIXELS ? kGroupBytes : kGroupBytesW;
@@ -356,7 +476,7 @@ __device__ __forceinline__ void convert_groups(const EncArgs& a, uint32_t stage,
 #pragma unroll
                 for (uint32_t i = 0; i < QS; ++i) {
                     const uint32_t n = q * QS + i;
-                    acc |= sq[i] << (3u + 8u * (n % EM));                      // stored pre-scaled by 8 (LUT entry offset)
+                    acc |= sq[i] << ((uint32_t)SH + 8u * (n % EM));            // stored pre-scaled (table entry offset)
                     if (n % EM == EM - 1u) {
                         if constexpr (EM == 2u) *(uint16_t*)(lds + dst + (n - 1u)) = (uint16_t)acc; else *(uint32_t*)(lds + dst + (n - 3u)) = acc;
                         acc = 0;
@@ -367,7 +487,7 @@ __device__ __forceinline__ void convert_groups(const EncArgs& a, uint32_t stage,
 #pragma unroll
                 for (uint32_t i = 0; i < QS; ++i) {
                     const uint32_t n = q * QS + i;
-                    acc |= sq[i] << (3u + 8u * (n % EM));
+                    acc |= sq[i] << ((uint32_t)SH + 8u * (n % EM));
                     if (n % EM == EM - 1u) {
                         const uint32_t u = u0 + n - (EM - 1u);
                         if (u >= S0 && u + EM <= S0 + TS) {
@@ -381,7 +501,7 @@ __device__ __forceinline__ void convert_groups(const EncArgs& a, uint32_t stage,
                 for (uint32_t i = 0; i < QS; ++i) {
                     uint32_t u = u0 + q * QS + i;
                     if constexpr (IL) { if (u >= a.n_sym) continue; u = il_perm(u, a); }
-                    if (u >= S0 && u < S0 + TS) lds[a.sym_off + (u - S0)] = (uint8_t)(sq[i] << 3);
+                    if (u >= S0 && u < S0 + TS) lds[a.sym_off + (u - S0)] = (uint8_t)(sq[i] << SH);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -401,10 +521,11 @@ __device__ __forceinline__ u16x2 pk_d9(u16x2 x)  { return (x * (uint16_t)228) >>
 __device__ __forceinline__ u16x2 pk_d27(u16x2 x) { return (x * (uint16_t)152) >> (uint16_t)12; }   // x <= 431
 __device__ __forceinline__ uint32_t pk_bits(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 
-// 9 reduced components (Y < 243, C < 81) of a triple pair -> 13 symbol pairs, each already multiplied by 8
+// 9 reduced components (Y < 243, C < 81) of a triple pair -> 13 symbol pairs, each already multiplied by SC
+template <int SC>
 __device__ __forceinline__ void px3x2_to_sym13x8(const u16x2* c, u16x2* s) {
     const u16x2 Y0 = c[0], B0 = c[1], R0 = c[2], Y1 = c[3], B1 = c[4], R1 = c[5], Y2 = c[6], B2 = c[7], R2 = c[8];
-    const uint16_t k8 = 8, k24 = 24, k72 = 72, k216 = 216;
+    const uint16_t k8 = SC, k24 = 3 * SC, k72 = 9 * SC, k216 = 27 * SC;
     u16x2 q, t;
     q = pk_d27(Y0); s[0] = Y0 * k8 - q * k216;            t = pk_d3(B0);  s[1] = q * k8 + (B0 - t * (uint16_t)3) * k72;  s[2] = t * k8;
     q = pk_d27(R0); s[3] = R0 * k8 - q * k216;            t = pk_d9(Y1);  s[4] = q * k8 + (Y1 - t * (uint16_t)9) * k24;  s[5] = t * k8;
@@ -417,10 +538,11 @@ __device__ __forceinline__ void px3x2_to_sym13x8(const u16x2* c, u16x2* s) {
 }
 
 // Convert the pixel triples that cover stream symbols [S0, S0+TS) from the stage buffer (image byte x = input byte b0 + x).
+template <int SC>
 __device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, uint32_t stage, uint64_t b0, uint32_t S0, uint32_t TS,
                                                       uint32_t lane, uint32_t wave, uint32_t nwv) {
     const uint32_t t_base = (S0 / 13u) & ~3u, t_end = (S0 + TS + 12u) / 13u;     // triples [t_base, t_end) touch the tile
-    const uint32_t wpp = nwv >> 1;                                                // waves per parity
+    const uint32_t wpp = min(a.p1_wpp, nwv >> 1);                                 // waves per parity (planner: just enough lanes)
     if (wave >= 2u * wpp) return;
     const uint32_t par = wave >= wpp ? 1u : 0u, wv = wave - par * wpp;
     for (uint32_t e0 = wv * 64u; t_base + 4u * e0 + par < t_end; e0 += wpp * 64u) {
@@ -432,7 +554,7 @@ __device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, uint32_t
         u16x2 over = {0, 0};
 #pragma unroll
         for (uint32_t i = 0; i < 9; ++i) {
-            h[i] = u16x2{*(const uint16_t*)(lds + src + 2u * i), *(const uint16_t*)(lds + srcB + 2u * i)};
+            h[i] = u16x2{*T3_LDS_PTR(uint16_t, src + 2u * i), *T3_LDS_PTR(uint16_t, srcB + 2u * i)};
             c[i] = (i % 3 == 0) ? h[i] : h[i] + (uint16_t)40;
             over |= __builtin_elementwise_sub_sat(c[i], (u16x2)((uint16_t)((i % 3 == 0) ? 242 : 80)));
         }
@@ -444,26 +566,28 @@ __device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, uint32_t
             }
         }
         u16x2 s[13];
-        px3x2_to_sym13x8(c, s);
-        // byte pairing: even triple -> shorts (s0,s1)..(s10,s11) + byte s12; odd triple -> byte s0 + shorts (s1,s2)..(s11,s12).
-        // 13 t + par is even and tile edges are multiples of 4, so a short never straddles a tile edge.
-        const uint32_t uA = 13u * tA, uB = uA + 26u;
-        const uint32_t dA = a.sym_off + (uA - S0), dB = dA + 26u;
-        const bool fullA = uA >= S0 && uA + 13u <= S0 + TS, fullB = uB >= S0 && uB + 13u <= S0 + TS;
-        const bool edge = __builtin_amdgcn_ballot_w64((liveA && !fullA) || (liveB && !fullB)) != 0;   // only the tile's first/last waves
+        px3x2_to_sym13x8<SC>(c, s);
+        // byte pairing: even triple -> shorts (s0,s1)..(s10,s11) + byte s12; odd triple -> byte s0 + shorts (s1,s2)..(s11,s12)
+        // (13 t + par is even).  Triples are written whole: the symbol buffer has kSymFront bytes of slack in front and 16
+        // behind, which take the symbols of the first/last triples that belong to the neighbouring tiles.
+        const uint32_t dA = a.sym_off + 13u * tA - S0, dB = dA + 26u;            // mod 2^32: may sit below sym_off (front slack)
         auto emit = [&](auto parc) {
             constexpr uint32_t P = decltype(parc)::value;
-#pragma unroll
-            for (uint32_t j = 0; j < 6; ++j) {
-                const uint32_t pr = pk_bits(s[2 * j + P]) | (pk_bits(s[2 * j + 1 + P]) << 8);     // low half: A's short, high half: B's
-                const uint32_t ia = P + 2u * j;
-                if (liveA && (!edge || (uA + ia >= S0 && uA + ia + 2u <= S0 + TS))) *(uint16_t*)(lds + dA + ia) = (uint16_t)pr;
-                if (liveB && (!edge || (uB + ia >= S0 && uB + ia + 2u <= S0 + TS))) *(uint16_t*)(lds + dB + ia) = (uint16_t)(pr >> 16);
-            }
             constexpr uint32_t is = P ? 0u : 12u;
+            uint32_t pr[6];
+#pragma unroll
+            for (uint32_t j = 0; j < 6; ++j) pr[j] = pk_bits(s[2 * j + P]) | (pk_bits(s[2 * j + 1 + P]) << 8);   // low half: A's short, high: B's
             const uint32_t single = pk_bits(s[is]);
-            if (liveA && (!edge || (uA + is >= S0 && uA + is < S0 + TS))) lds[dA + is] = (uint8_t)single;
-            if (liveB && (!edge || (uB + is >= S0 && uB + is < S0 + TS))) lds[dB + is] = (uint8_t)(single >> 16);
+            if (liveA) {
+#pragma unroll
+                for (uint32_t j = 0; j < 6; ++j) *T3_LDS_WPTR(uint16_t, dA + P + 2u * j) = (uint16_t)pr[j];
+                *T3_LDS_WPTR(uint8_t, dA + is) = (uint8_t)single;
+            }
+            if (liveB) {
+#pragma unroll
+                for (uint32_t j = 0; j < 6; ++j) *T3_LDS_WPTR(uint16_t, dB + P + 2u * j) = (uint16_t)(pr[j] >> 16);
+                *T3_LDS_WPTR(uint8_t, dB + is) = (uint8_t)(single >> 16);
+            }
         };
         if (par) emit(std::integral_constant<uint32_t, 1>{}); else emit(std::integral_constant<uint32_t, 0>{});
     }
@@ -487,6 +611,7 @@ __device__ __forceinline__ void barrier_input(uint32_t younger) {
         case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
         case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
         default: barrier_all(); break;
     }
 }
@@ -496,6 +621,7 @@ __device__ __forceinline__ void barrier_input(uint32_t younger) {
 template <int FE, bool IL, int RSEL>
 __device__ __forceinline__ void encode_body(const EncArgs& a) {
     constexpr uint32_t GS = FE == FE_PIXELS ? kGroupSyms : kGroupSymsW;      // symbols per lane group
+    constexpr int SH = RSEL != 0 ? 2 : 3;                                     // symbol pre-scale: 4-byte T entries (MFMA) / 8-byte LUT entries
     const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
     const uint32_t TS = 9u * a.Lq;
 
@@ -510,6 +636,8 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
         }
 #pragma unroll
         for (int b = 0; b < 10; ++b) *(uint32_t*)(lds + 288 + 4 * b) = a.band_first[b];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) *(uint32_t*)(lds + 336 + 4 * i) = a.scr[i];
     }
     for (uint32_t i = tid * 16u; i < a.lut_bytes; i += nthr * 16u)
         *(uint4*)(lds + kLdsHdr + i) = *(const uint4*)((const uint8_t*)a.lut_img + i);
@@ -520,6 +648,12 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             for (uint32_t i = 0; i < 96; ++i) if (i < a.hdr_syms) a.frame_out[i] = a.hdr[i];
         }
         if (tid < a.pad_bytes) a.frame_out[a.out_syms + tid] = 0;
+    }
+
+    v4i Afr[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};                   // single-k kernels: the parity matrix lives in 12 VGPRs
+    if constexpr (RSEL != 0) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) Afr[s] = ((const v4i*)a.afrag)[s * 64 + lane];
     }
 
 #ifdef T3_STAMPS   // diagnostic build: per-phase cycle sums of wave 0 (never in the product build)
@@ -536,24 +670,40 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
         if (blockIdx.x < a.n_tiles) stage_input<FE>(a, a.stage_off, first_group(blockIdx.x * TS), (blockIdx.x * TS + TS + GS - 1u) / GS, lane, wave, nwv);
     }
     uint32_t younger = 0;                                                    // VMEM ops this wave issued after its last prefetch
-    for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    // Tiles are handed out dynamically: the three workgroups of a CU progress at different speeds (oldest wave first),
+    // up to 1.6x apart.  The first tile is blockIdx.x, every further one a ticket.  One counter serves ~11 ns per draw
+    // (memory-side atomic), too slow for 14k tiles, so workgroups and tiles are split into n_classes classes by index
+    // modulo n_classes, each with its own counter (class == XCD under round-robin dispatch, but nothing relies on it).
+    const bool dyn = !IL && a.tile_ctr != nullptr;
+    const uint32_t NC = a.n_classes, cls = blockIdx.x % NC;
+    uint32_t* const ctr = a.tile_ctr + 64u * cls;                              // one counter per class, 256 B apart
+    const uint32_t j0 = (gridDim.x - cls + NC - 1u) / NC;                      // workgroups in this class = first ticketed index
+    uint32_t pend = 0;                                                         // thread 0: ticket of the tile after the next one
+    if (dyn && tid == 0) pend = atomicAdd(ctr, 1u);
+    for (uint32_t tile = blockIdx.x, nxt = 0; tile < a.n_tiles; tile = nxt) {
         const uint32_t S0 = tile * TS;
         const uint32_t stage = a.stage_off;
         // ---------------- phase 1: input -> stream-ordered symbols in LDS ----------------
         if constexpr (!IL) {
             barrier_input(younger);                                           // this tile's input has landed, everyone left phase 2
             T3_STAMP(0);
+            uint32_t ticket = 0;
+            if (dyn && tid == 0) ticket = atomicAdd(ctr, 1u);                 // drawn two tiles ahead: its latency hides under a whole tile
 #ifndef T3_ABL_NO_P1
-            if constexpr (FE == FE_PIXELS) convert_pixels_packed(a, stage, ((uint64_t)first_group(S0) * kGroupBytes) & ~15ull, S0, TS, lane, wave, nwv);
-            else convert_groups<FE, false>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, tid, nthr);
+            if constexpr (FE == FE_PIXELS) convert_pixels_packed<(1 << SH)>(a, stage, ((uint64_t)first_group(S0) * kGroupBytes) & ~15ull, S0, TS, lane, wave, nwv);
+            else convert_groups<FE, false, SH>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, tid, nthr);
 #endif
             T3_STAMP(5);                                                      // (diagnostic) this wave's conversion
+            if (dyn && tid == 0) { *(uint32_t*)(lds + 328) = cls + NC * (j0 + pend); pend = ticket; }
             barrier_lds();                                                    // symbols complete; the stage buffer is free again
             T3_STAMP(1);
-            const uint32_t nxt = tile + gridDim.x;                            // next tile's input streams in under phase 2
+            nxt = dyn ? __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + 328)) : tile + gridDim.x;   // its input streams in under phase 2
+#ifndef T3_ABL_NO_PREFETCH
             if (nxt < a.n_tiles) stage_input<FE>(a, stage, first_group(nxt * TS), (nxt * TS + TS + GS - 1u) / GS, lane, wave, nwv);
+#endif
             T3_STAMP(4);
         } else {
+            nxt = tile + gridDim.x;
             __syncthreads();                                                  // everyone left phase 2 of the previous tile
             for (uint32_t i = tid * 16u; i < TS; i += nthr * 16u) *(uint4*)(lds + a.sym_off + i) = make_uint4(0, 0, 0, 0);
             uint32_t u_lo = S0, u_hi = S0;                                   // pre-interleave symbols this tile needs: whole row segments
@@ -566,7 +716,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
                 stage_input<FE>(a, stage, gc, gc_hi, lane, wave, nwv);
                 __syncthreads();
                 T3_STAMP(0);
-                convert_groups<FE, true>(a, stage, gc, gc, gc_hi, S0, TS, tid, nthr);
+                convert_groups<FE, true, SH>(a, stage, gc, gc, gc_hi, S0, TS, tid, nthr);
                 __syncthreads();
                 T3_STAMP(1);
             }
@@ -579,8 +729,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             const uint32_t item = tid;                                        // one lane = one block, dealt linearly across the bands
             bool did = false;
             if constexpr (RSEL != 0) {
-                const uint32_t b = fdiv(item, a.div_nb), m = item - b * a.nb_uniform;
-                if (item < a.n_items) did = phase2_band<RSEL, true>(a, tile, b, m, a.nb_uniform);
+                younger = phase2_mfma<RSEL>(a, tile, wave, lane, Afr);
             } else if (item < a.n_items) {
                 uint32_t b = 0;
 #pragma unroll
@@ -593,16 +742,23 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
                     default: did = phase2_band<8, false>(a, tile, b, m, nbt); break;
                 }
             }
-            // single-k kernels: a wave with any valid block issues exactly kP2Stores store instructions after the prefetch
-            // (otherwise none: younger = 0 over-waits, which is safe); the mixed kernel does not count
-            if (RSEL != 0 && __builtin_amdgcn_ballot_w64(did) != 0) younger = kP2Stores;
+            // single-k kernels count the store instructions issued after the prefetch (see phase2_mfma); the mixed kernel
+            // does not (younger = 0 over-waits, which is safe)
+            (void)did;
         }
 #endif
         T3_STAMP(2);
     }
+    if (dyn && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this workgroup's last ticket draw has completed
+        if (atomicAdd(a.tile_ctr + 64u * NC, 1u) == gridDim.x - 1u) {          // ... and so has everyone else's: re-arm for the next launch
+            for (uint32_t c = 0; c <= NC; ++c) __hip_atomic_store(a.tile_ctr + 64u * c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 #ifdef T3_STAMPS
     if (tid == 0 && a.dbg) {
-        uint64_t* d = a.dbg + 8ull * blockIdx.x;
+        uint64_t* d = a.dbg + 16ull * blockIdx.x;
+        d[8] = __builtin_amdgcn_s_getreg(31 << 11 | 4); d[9] = __builtin_amdgcn_s_getreg(31 << 11 | 20);   // HW_ID, XCC_ID
         d[0] = st_acc[0]; d[1] = st_acc[1]; d[2] = st_acc[2]; d[3] = st_rt0;
         d[4] = __builtin_amdgcn_s_memtime() - st_t0; d[5] = __builtin_amdgcn_s_memrealtime() - st_rt0; d[6] = st_acc[4]; d[7] = st_acc[5];
     }
@@ -610,10 +766,10 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 }
 
 #ifndef T3_ENC_WAVES_PER_EU
-#define T3_ENC_WAVES_PER_EU 6   // <= 80 VGPRs: two 9-wave workgroups per CU place 3+3 waves on one SIMD
+#define T3_ENC_WAVES_PER_EU 6   // <= 80 VGPRs: three 8-wave workgroups per CU
 #endif
 template <int FE, bool IL, int RSEL>
-__global__ __launch_bounds__(640, T3_ENC_WAVES_PER_EU) void encode_kernel_k(const EncArgs a) { encode_body<FE, IL, RSEL>(a); }
+__global__ __launch_bounds__(512, T3_ENC_WAVES_PER_EU) void encode_kernel_k(const EncArgs a) { encode_body<FE, IL, RSEL>(a); }
 template <int FE, bool IL>
 __global__ __launch_bounds__(1024) void encode_kernel_mixed(const EncArgs a) { encode_body<FE, IL, 0>(a); }
 
