@@ -297,7 +297,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 struct __attribute__((packed, aligned(2))) U32a2 { uint32_t v; };
-struct __attribute__((packed, aligned(2))) U96a2 { uint32_t v[3]; };
+struct __attribute__((packed, aligned(2))) U128a2 { uint32_t v[4]; };
 constexpr uint32_t kMfmaModOff = 3 * 4096, kMfmaScr = 336;     // must match t3_host.hpp; scrambler dwords sit in the LDS header
 
 template <int R>
@@ -373,23 +373,27 @@ __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t tile,
         uint32_t W0 = W[0];
         if (r.body_off == 0 && mg == 0 && h == 0)               // body symbols 0 and 1 see the pre-period states (exact whatever the seed; OLD:81-87)
             W0 = (W0 & 0xFFFF0000u) | add13(dd0 >> 2, a.pre0) | (add13(dd1 >> 2, a.pre1) << 8);
-        // Lane (n, h) holds bytes [8s + 4h, +4) of block n.  One half-wave exchange gives every lane 12 consecutive bytes
-        // (h = 0: bytes 0..11, h = 1: bytes 12..23 and the last two), so a set goes out in one 12-byte and one 2-byte store
-        // per lane instead of three scattered dwords: a quarter of the cache-line requests.
+        // Lane (n, h) holds bytes [8s + 4h, +4) of block n.  Two half-wave exchanges give the lower lane bytes 0..15 and the
+        // upper lane bytes 10..25 of the block: ONE 16-byte store per lane covers the 26 bytes (bytes 10..15 are written by
+        // both, with the same values), instead of three scattered dwords and a short -- an eighth of the cache-line requests.
         const auto sw = __builtin_amdgcn_permlane32_swap(W0, W2, false, false);   // upper half of W0 (bytes 4..7) <-> lower half of W2 (bytes 16..19)
         const uint32_t Xa = sw[0], Xb = sw[1];                                    // h=0: Xa = bytes 0..3, Xb = 4..7;   h=1: Xa = 16..19, Xb = 20..23
+        const auto sw1 = __builtin_amdgcn_permlane32_swap(W[1], W[1], false, false);
+        const uint32_t oW1 = h ? sw1[0] : sw1[1];                                  // the partner's W[1]: h=0 gets bytes 12..15, h=1 bytes 8..11
         const uint32_t S0 = h ? W[1] : Xa, S1 = h ? Xa : Xb, S2 = h ? Xb : W[1];   // h=0: 0..3, 4..7, 8..11;  h=1: 12..15, 16..19, 20..23
+        U128a2 E;
+        E.v[0] = h ? __builtin_amdgcn_alignbit(S0, oW1, 16) : S0;                  // h=1: bytes 10..13
+        E.v[1] = h ? __builtin_amdgcn_alignbit(S1, S0, 16) : S1;
+        E.v[2] = h ? __builtin_amdgcn_alignbit(S2, S1, 16) : S2;
+        E.v[3] = h ? __builtin_amdgcn_alignbit(tail, S2, 16) : oW1;                // h=1: bytes 22..25
 #ifdef T3_ABL_NO_STORE
-        if (valid && a.n_tiles == 0xFFFFFFFFu) {
+        if (valid && a.n_tiles == 0xFFFFFFFFu)
 #else
-        if (valid) {
+        if (valid)
 #endif
-            uint8_t* G = a.body_out + r.body_off + 26ull * mg + 12u * h;          // 2-byte aligned
-            ((U96a2*)G)->v[0] = S0; ((U96a2*)G)->v[1] = S1; ((U96a2*)G)->v[2] = S2;
-            if (h) *(uint16_t*)(G + 12) = (uint16_t)tail;                          // bytes 24, 25 of the block
-        }
+            *(U128a2*)(a.body_out + r.body_off + 26ull * mg + 10u * h) = E;        // 2-byte aligned
 #ifndef T3_ABL_NO_STORE
-        issued += 2u;
+        issued += 1u;
 #endif
     }
     return issued;
