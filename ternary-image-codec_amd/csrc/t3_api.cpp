@@ -97,8 +97,8 @@ uint64_t gcd64(uint64_t a, uint64_t b) { while (b) { uint64_t t = a % b; a = b; 
 // ------------------------------------------------------------------------------------------------
 struct EncLaunch { EncArgs a; uint32_t block; int rsel; };   // rsel = 26-k when all bands of the launch share k, else 0
 
-// Phase 1 (pixels) gives a lane two pixel triples of one parity, 4 triples apart per lane: waves per parity that cover the
-// worst-placed tile of TS symbols (tile starts cycle through S0 mod 52)
+// Phase 1 (pixels) gives a lane four consecutive pixel triples: waves that cover the worst-placed tile of TS symbols
+// (tile starts cycle through S0 mod 52)
 uint32_t p1_waves_per_parity(uint32_t TS) {
     uint32_t worst = 0;
     for (uint32_t t = 0; t < 52; ++t) {
@@ -109,11 +109,7 @@ uint32_t p1_waves_per_parity(uint32_t TS) {
     return (worst + 63) / 64;
 }
 
-// mfma_sets != 0: the matrix-core layout (single k, all nine bands): wave = band, tile = 32 * mfma_sets blocks per band,
-// nine per-wave output images behind the stage buffer; fails when that does not fit `mfma_budget` bytes of LDS
-constexpr uint32_t kOutStride = 864;   // must match t3_kernels.hip
-bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, int fe, const LutImage& lut, EncLaunch& out,
-                    uint32_t mfma_sets = 0, uint32_t mfma_budget = 0) {
+bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, int fe, const LutImage& lut, EncLaunch& out) {
     EncArgs& a = out.a; memset(&a, 0, sizeof a);
     const uint32_t GS = fe == FE_PIXELS ? kGroupSyms : kGroupSymsW, GB = fe == FE_PIXELS ? kGroupBytes : kGroupBytesW;
     uint64_t Lk = 2;
@@ -121,13 +117,6 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     uint32_t lut_bytes = lut.bytes;
     // pick q (even): tile = 9*Lk*q stream symbols; band b then owns Lk*q/k_b blocks = that/2 lane pairs
     double best_score = -1; uint32_t best_q = 0;
-    if (mfma_sets) {
-        const uint64_t Lq = Lk * 32u * mfma_sets / (Lk / L.band_k[0]);          // Lk = lcm(2, k) = k for the even k's in use
-        const uint32_t groups = (uint32_t)(9 * Lq / GS) + 6, stage = groups * GB + 1024 + 32;
-        const uint32_t total = kLdsHdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq)) + 16 + round16(stage) + 9 * kOutStride;
-        if (Lq % Lk != 0 || total > mfma_budget || (fe == FE_PIXELS && 2 * p1_waves_per_parity((uint32_t)(9 * Lq)) > 9)) return false;
-        best_q = (uint32_t)(Lq / Lk);
-    }
     for (int pass = 0; pass < 2 && !best_q; ++pass) {
         const uint32_t budget = pass == 0 ? 53u * 1024u : 160u * 1024u;     // <= 53 KiB: three workgroups per CU
         for (uint32_t q = 2; q <= 4096; q += 2) {
@@ -140,13 +129,13 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
             waves = (blocks_total + 63) / 64;                          // lanes are dealt to blocks linearly across bands
             if (waves > (pass == 0 ? 8u : (uint32_t)kMaxWaves)) break;   // pass 0: 512-thread workgroups, three per CU
             const uint32_t groups = (uint32_t)(9 * Lq / GS) + 6, stage = groups * GB + 1024 + 32;   // +1 KiB: LDS-DMA pieces are whole
-            const uint32_t total = kLdsHdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq)) + 16 + round16(stage);
+            const uint32_t total = kLdsHdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq)) + kSymBack + round16(stage);
             (void)outb;
             if (total > budget) break;
             // wave-instructions per stream symbol: phase 2 costs ~180 per wave, phase 1 (pixels) ~120 per wave-iteration
             const uint32_t wpp = p1_waves_per_parity((uint32_t)(9 * Lq));
-            if (fe == FE_PIXELS && 2 * wpp > std::max(waves, 4u)) continue;
-            const double cost = (180.0 * waves + (fe == FE_PIXELS ? 240.0 * wpp : 180.0 * waves)) / (double)(9 * Lq);
+            if (fe == FE_PIXELS && wpp > std::max(waves, 4u)) continue;
+            const double cost = (180.0 * waves + (fe == FE_PIXELS ? 220.0 * wpp : 180.0 * waves)) / (double)(9 * Lq);
             const double score = 1.0 / cost + 1e-9 * (double)Lq;
             if (score > best_score) { best_score = score; best_q = q; }
         }
@@ -155,7 +144,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     const uint32_t Lq = (uint32_t)(Lk * best_q);
     a.Lq = Lq; a.lut_bytes = round16(lut_bytes);
     uint32_t off = kLdsHdr + a.lut_bytes;
-    off += kSymFront; a.sym_off = off; off += round16(9 * Lq) + 16;   // slack either side: phase 1 writes whole pixel triples
+    off += kSymFront; a.sym_off = off; off += round16(9 * Lq) + kSymBack;   // slack either side: phase 1 writes whole pixel triples
     a.stage_off = off;
     a.stage_groups = 9 * Lq / GS + 6;
     uint32_t outb = 0, nw = 0, n_tiles = 0;
@@ -173,7 +162,6 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     { uint32_t acc = 0; for (int b = 0; b < 9; ++b) { a.band_first[b] = acc; acc += a.band_nb_tile[b]; } a.band_first[9] = acc; }
     a.stage_stride = round16(a.stage_groups * GB + 1024 + 32);
     a.lds_bytes = a.stage_off + a.stage_stride;
-    if (mfma_sets) { a.p2_sets = mfma_sets; a.out_off = a.lds_bytes; a.lds_bytes += 9 * kOutStride; }
     a.n_sym = (uint32_t)L.n_sym;
     const ScrCycle sc = scrambler_cycle(cfg.seed_a, cfg.seed_b, cfg.seed_s0);
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
@@ -184,7 +172,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
         a.il_w = cfg.tile_w; a.il_A = (uint32_t)std::min<uint64_t>(A, std::max<uint64_t>(L.n_sym, 1));
         a.div_A = to_dev(fastdiv(a.il_A)); a.div_w = to_dev(fastdiv(a.il_w));
     }
-    out.block = mfma_sets ? 576u : 64u * std::max<uint32_t>((nw + 63) / 64, 4u);
+    out.block = 64u * std::max<uint32_t>((nw + 63) / 64, 4u);
     a.p1_wpp = p1_waves_per_parity(9 * Lq);
     out.rsel = 0;
     { int k0 = 0; bool same = true; for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) { if (!k0) k0 = L.band_k[b]; else if (k0 != L.band_k[b]) same = false; } if (same && k0 && band_mask == 0x1FF) out.rsel = 26 - k0; }

@@ -9,7 +9,8 @@ enum FrontEnd : int { FE_PIXELS = 0, FE_WORDS = 1 };
 
 constexpr int kMaxWaves = 16;            // 1024-thread workgroup
 constexpr int kLdsHdr = 512;            // LDS header: 9 band rows (32 B) + wave roles
-constexpr int kSymFront = 64;           // slack in front of the LDS symbol buffer (phase 1 writes whole pixel triples)
+constexpr int kSymFront = 64;           // slack in front of the LDS symbol buffer (phase 1 writes whole pixel triples) ...
+constexpr int kSymBack = 64;            // ... and behind it
 constexpr int kGroupSyms = 26;           // symbols one phase-1 lane produces from pixels: 6 px = 36 B -> 26 symbols
 constexpr int kGroupBytes = 36;
 constexpr int kGroupSymsW = 52;          // from raw words: 6 words = 54 B -> 52 symbols
@@ -53,8 +54,7 @@ struct EncArgs {
     uint8_t   hdr[96];
     uint32_t* tile_ctr;             // ticket counters [64 * class], then workgroups-finished at [64 * n_classes] (last one re-zeroes); null = static striding
     uint32_t  n_classes;            // ticket classes (<= grid)
-    uint32_t  p1_wpp;               // phase 1 (pixels): waves per triple parity that cover a tile
-    uint32_t  p2_sets, out_off;     // single-k launches: sets of 32 blocks per wave (= band) and tile; LDS offset of the per-wave output images
+    uint32_t  p1_wpp;               // phase 1 (pixels): waves that cover a tile (one lane = four pixel triples)
     uint64_t* dbg;                  // diagnostic stamp builds only (T3_STAMPS); null in the product
 };
 

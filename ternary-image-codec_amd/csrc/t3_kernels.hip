@@ -22,6 +22,7 @@ extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 #define T3_LDS_WPTR(T, a) ((__attribute__((address_space(3))) T*)(uintptr_t)(a))
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ uint32_t lds_u8(uint32_t a)  { return *T3_LDS_PTR(uint8_t, a); }
 __device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *T3_LDS_PTR(uint32_t, a); }
 
@@ -542,58 +543,69 @@ __device__ __forceinline__ void px3x2_to_sym13x8(const u16x2* c, u16x2* s) {
 }
 
 // Convert the pixel triples that cover stream symbols [S0, S0+TS) from the stage buffer (image byte x = input byte b0 + x).
+// A lane takes FOUR consecutive triples (12 pixels, 72 input bytes -> 52 symbols): its input is nine aligned 8-byte reads, its
+// output thirteen aligned dwords.  Triples 0 and 2 share registers as low/high halves, so do 1 and 3 (same parity each).
+// Triples are written whole: the symbol buffer has kSymFront bytes of slack in front and 64 behind, which take the symbols of
+// the first/last triples that belong to the neighbouring tiles (and of the up to three triples past the tile's last one).
 template <int SC>
 __device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, uint32_t stage, uint64_t b0, uint32_t S0, uint32_t TS,
                                                       uint32_t lane, uint32_t wave, uint32_t nwv) {
     const uint32_t t_base = (S0 / 13u) & ~3u, t_end = (S0 + TS + 12u) / 13u;     // triples [t_base, t_end) touch the tile
-    const uint32_t wpp = min(a.p1_wpp, nwv >> 1);                                 // waves per parity (planner: just enough lanes)
-    if (wave >= 2u * wpp) return;
-    const uint32_t par = wave >= wpp ? 1u : 0u, wv = wave - par * wpp;
-    for (uint32_t e0 = wv * 64u; t_base + 4u * e0 + par < t_end; e0 += wpp * 64u) {
-        const uint32_t tA = t_base + 4u * (e0 + lane) + par, tB = tA + 2u;
-        const bool liveA = tA < t_end, liveB = tB < t_end;
-        const uint32_t src = stage + (uint32_t)((uint64_t)(liveA ? tA : t_base) * 18u - b0);
-        const uint32_t srcB = liveB ? src + 36u : src;
-        u16x2 h[9], c[9];
-        u16x2 over = {0, 0};
+    const uint32_t nw1 = min(a.p1_wpp, nwv);                                      // waves that convert (planner: just enough lanes)
+    if (wave >= nw1) return;
+    for (uint32_t e0 = wave * 64u; t_base + 4u * e0 < t_end; e0 += nw1 * 64u) {
+        const uint32_t t = t_base + 4u * (e0 + lane);
+        const bool live = t < t_end;
+        const uint32_t src = stage + (uint32_t)((uint64_t)(live ? t : t_base) * 18u - b0);   // 8-byte aligned
+        uint32_t D[18];
 #pragma unroll
-        for (uint32_t i = 0; i < 9; ++i) {
-            h[i] = u16x2{*T3_LDS_PTR(uint16_t, src + 2u * i), *T3_LDS_PTR(uint16_t, srcB + 2u * i)};
-            c[i] = (i % 3 == 0) ? h[i] : h[i] + (uint16_t)40;
-            over |= __builtin_elementwise_sub_sat(c[i], (u16x2)((uint16_t)((i % 3 == 0) ? 242 : 80)));
-        }
-        if (__builtin_amdgcn_ballot_w64(pk_bits(over) != 0u) != 0) {             // out-of-range quantised values: exact general reduction
+        for (uint32_t i = 0; i < 9; ++i) { const u32x2 v = *T3_LDS_PTR(u32x2, src + 8u * i); D[2 * i] = v.x; D[2 * i + 1] = v.y; }
+        // halves whose triple lies past the tile's last one hold stale bytes: keep them out of the range check
+        const uint32_t liveA = t + 2u < t_end ? 0xFFFFFFFFu : 0x0000FFFFu, liveB = (t + 1u < t_end ? 0x0000FFFFu : 0u) | (t + 3u < t_end ? 0xFFFF0000u : 0u);
+        u16x2 sA[13], sB[13];
+#pragma unroll
+        for (uint32_t pair = 0; pair < 2; ++pair) {                               // pair 0 = triples (0, 2), pair 1 = triples (1, 3)
+            u16x2 h[9], c[9];
+            u16x2 over = {0, 0};
 #pragma unroll
             for (uint32_t i = 0; i < 9; ++i) {
-                const uint32_t lo = h[i].x, hi = h[i].y;
-                c[i] = (i % 3 == 0) ? u16x2{(uint16_t)red_y(lo), (uint16_t)red_y(hi)} : u16x2{(uint16_t)red_c(lo), (uint16_t)red_c(hi)};
+                const uint32_t u = 9u * pair + i;                                 // 16-bit index of the low-half component; the high half sits 18 further
+                const uint32_t w = __builtin_amdgcn_perm(D[9u + u / 2u], D[u / 2u], (u & 1u) ? 0x07060302u : 0x05040100u);
+                h[i] = __builtin_bit_cast(u16x2, w);
+                c[i] = (i % 3 == 0) ? h[i] : h[i] + (uint16_t)40;
+                over |= __builtin_elementwise_sub_sat(c[i], (u16x2)((uint16_t)((i % 3 == 0) ? 242 : 80)));
             }
+            if (__builtin_amdgcn_ballot_w64(live && (pk_bits(over) & (pair ? liveB : liveA)) != 0u) != 0) {   // out-of-range quantised values: exact general reduction
+#pragma unroll
+                for (uint32_t i = 0; i < 9; ++i) {
+                    const uint32_t lo = h[i].x, hi = h[i].y;
+                    c[i] = (i % 3 == 0) ? u16x2{(uint16_t)red_y(lo), (uint16_t)red_y(hi)} : u16x2{(uint16_t)red_c(lo), (uint16_t)red_c(hi)};
+                }
+            }
+            px3x2_to_sym13x8<SC>(c, pair ? sB : sA);
         }
-        u16x2 s[13];
-        px3x2_to_sym13x8<SC>(c, s);
-        // byte pairing: even triple -> shorts (s0,s1)..(s10,s11) + byte s12; odd triple -> byte s0 + shorts (s1,s2)..(s11,s12)
-        // (13 t + par is even).  Triples are written whole: the symbol buffer has kSymFront bytes of slack in front and 16
-        // behind, which take the symbols of the first/last triples that belong to the neighbouring tiles.
-        const uint32_t dA = a.sym_off + 13u * tA - S0, dB = dA + 26u;            // mod 2^32: may sit below sym_off (front slack)
-        auto emit = [&](auto parc) {
-            constexpr uint32_t P = decltype(parc)::value;
-            constexpr uint32_t is = P ? 0u : 12u;
-            uint32_t pr[6];
+        // 16-bit pieces of the 52 output bytes (low half: first triple of the pair, high half: second):
+        //   E_j = (s_2j, s_2j+1) of triples 0/2;  O_j = (s_2j+1, s_2j+2) of triples 1/3;  X = (s_12 of 0/2, s_0 of 1/3)
+        uint32_t E[6], O[6];
 #pragma unroll
-            for (uint32_t j = 0; j < 6; ++j) pr[j] = pk_bits(s[2 * j + P]) | (pk_bits(s[2 * j + 1 + P]) << 8);   // low half: A's short, high: B's
-            const uint32_t single = pk_bits(s[is]);
-            if (liveA) {
+        for (uint32_t j = 0; j < 6; ++j) {
+            E[j] = pk_bits(sA[2 * j]) | (pk_bits(sA[2 * j + 1]) << 8);
+            O[j] = pk_bits(sB[2 * j + 1]) | (pk_bits(sB[2 * j + 2]) << 8);
+        }
+        const uint32_t X = pk_bits(sA[12]) | (pk_bits(sB[0]) << 8);
+        constexpr uint32_t LL = 0x05040100u, HH = 0x07060302u, LH = 0x07060100u;   // v_perm(S0, S1): result = (S1.lo|S0.lo), (S1.hi|S0.hi), (S1.lo|S0.hi)
+        uint32_t o[13];
+        o[0] = __builtin_amdgcn_perm(E[1], E[0], LL);  o[1] = __builtin_amdgcn_perm(E[3], E[2], LL);  o[2] = __builtin_amdgcn_perm(E[5], E[4], LL);
+        o[3] = __builtin_amdgcn_perm(O[0], X, LL);     o[4] = __builtin_amdgcn_perm(O[2], O[1], LL);  o[5] = __builtin_amdgcn_perm(O[4], O[3], LL);
+        o[6] = __builtin_amdgcn_perm(E[0], O[5], LH);
+        o[7] = __builtin_amdgcn_perm(E[2], E[1], HH);  o[8] = __builtin_amdgcn_perm(E[4], E[3], HH);  o[9] = __builtin_amdgcn_perm(X, E[5], HH);
+        o[10] = __builtin_amdgcn_perm(O[1], O[0], HH); o[11] = __builtin_amdgcn_perm(O[3], O[2], HH); o[12] = __builtin_amdgcn_perm(O[5], O[4], HH);
+        if (live) {
+            const uint32_t dst = a.sym_off + 13u * t - S0;                        // dword aligned; may sit below sym_off (front slack)
 #pragma unroll
-                for (uint32_t j = 0; j < 6; ++j) *T3_LDS_WPTR(uint16_t, dA + P + 2u * j) = (uint16_t)pr[j];
-                *T3_LDS_WPTR(uint8_t, dA + is) = (uint8_t)single;
-            }
-            if (liveB) {
-#pragma unroll
-                for (uint32_t j = 0; j < 6; ++j) *T3_LDS_WPTR(uint16_t, dB + P + 2u * j) = (uint16_t)(pr[j] >> 16);
-                *T3_LDS_WPTR(uint8_t, dB + is) = (uint8_t)(single >> 16);
-            }
-        };
-        if (par) emit(std::integral_constant<uint32_t, 1>{}); else emit(std::integral_constant<uint32_t, 0>{});
+            for (uint32_t j = 0; j < 6; ++j) *T3_LDS_WPTR(u32x2a4, dst + 8u * j) = u32x2a4{o[2 * j], o[2 * j + 1]};
+            *T3_LDS_WPTR(uint32_t, dst + 48u) = o[12];
+        }
     }
 }
 
