@@ -392,7 +392,13 @@ __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t tile,
 #else
         if (valid)
 #endif
+#if defined(T3_ABL_STORE_LOCAL)
+            *(U128a2*)(a.body_out + 26u * (item & 511u) + 10u * h + 16384u * (blockIdx.x & 1023u)) = E;   // timing only: L2-resident target
+#elif defined(T3_ABL_STORE_ALIGNED)
+            *(u32x4*)(a.body_out + ((r.body_off + 26ull * mg) & ~15ull) + 16u * h) = __builtin_bit_cast(u32x4, E);   // timing only: 16-byte aligned
+#else
             *(U128a2*)(a.body_out + r.body_off + 26ull * mg + 10u * h) = E;        // 2-byte aligned
+#endif
 #ifndef T3_ABL_NO_STORE
         issued += 1u;
 #endif
