@@ -116,7 +116,7 @@ def main():
             return
         seen = t3.DecoderContext(mode=t3.MODE_FIXED).cfg_last_seen
         rc, n = t3.decode_profile_dev(d_fenc.data_ptr(), n_fenc, seen, d_back.data_ptr(), NPX, True, stream)
-        assert rc == 0 and n == NPX, (rc, n)
+        assert args.no_verify or (rc == 0 and n == NPX), (rc, n)
         if ev is not None:
             ev[2].record(stream)
         t3.frame_record_dev(d_enc.data_ptr(), n_enc, i * world + rank, cfg, d_recs[i % len(d_recs)].data_ptr(), d_scr.data_ptr(), 64, stream)
@@ -150,7 +150,7 @@ def main():
         assert ol.fnv_hex(enc) == GOLD_HASH_C2, "encoded stream does not match the reference hash"
     if not args.encode_only:
         back = d_back[: NPX * 6].cpu().numpy().view(ol.PIXEL_DT)
-        assert np.array_equal(back, px), "FIXED decode did not recover the frame"
+        assert args.no_verify or np.array_equal(back, px), "FIXED decode did not recover the frame"
         index = sf.assemble_index(gathered if world > 1 else d_recs, 0)
         assert len(index) == world * args.steps and [r.frame_idx for r in index] == list(range(world * args.steps))
         mine = index[(args.steps - 1) * world + rank]          # frames are dealt round-robin: frame f lives on rank f % world

@@ -26,6 +26,7 @@ uint32_t* d_zpow = nullptr;     // CRC "append 2^j zero bytes" operators
 uint32_t* d_crc_acc = nullptr;  // [0] xor accumulator, [1] symbol sum
 FxTables* d_fxtab = nullptr;    // field tables of the fused FIXED decoder
 uint32_t* d_synd_lut[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t synd_lut_bytes[4] = {0, 0, 0, 0};   // per k index
+uint32_t* d_roots[4] = {nullptr, nullptr, nullptr, nullptr};   // per k index: the Chien search (OLD:611-623) of every locator, tabulated
 
 int k_index(int k) { return k == 24 ? 0 : k == 22 ? 1 : k == 20 ? 2 : k == 18 ? 3 : -1; }
 
@@ -41,8 +42,28 @@ int decode_fixed_fused(const void* d_in, uint64_t n_in, const t3_cfg& cfg, const
         HIPCHK(hipMalloc((void**)&d_synd_lut[ki], synd_lut_bytes[ki]));
         HIPCHK(hipMemcpy(d_synd_lut[ki], img.data(), synd_lut_bytes[ki], hipMemcpyHostToDevice));
     }
+    if (!d_roots[ki]) {
+        // sigma_0 = 1 always (Berlekamp-Massey), so sigma is its t = r/2 higher coefficients: 27^t locators (80 KB for
+        // RS(26,20), 2 MB for RS(26,18)).  Entry = the 26-bit mask of positions i with sigma(alpha^-i) = 0.
+        const Field& F = field(); const int t = (26 - k) / 2;
+        size_t n = 1; for (int i = 0; i < t; ++i) n *= 27;
+        std::vector<uint32_t> tbl(n);
+        for (size_t idx = 0; idx < n; ++idx) {
+            uint8_t sg[5] = {1, 0, 0, 0, 0}; { size_t v = idx; for (int q = 1; q <= t; ++q) { sg[q] = (uint8_t)(v % 27); v /= 27; } }
+            uint32_t mask = 0;
+            for (int i = 0; i < 26; ++i) {
+                const uint8_t x = F.t.exp[i == 0 ? 0 : 26 - i];
+                uint8_t acc = sg[t];
+                for (int q = t - 1; q >= 0; --q) acc = F.t.add[F.t.mul[acc * 27 + x] * 27 + sg[q]];
+                if (acc == 0) mask |= 1u << i;
+            }
+            tbl[idx] = mask;
+        }
+        HIPCHK(hipMalloc((void**)&d_roots[ki], n * 4));
+        HIPCHK(hipMemcpy(d_roots[ki], tbl.data(), n * 4, hipMemcpyHostToDevice));
+    }
     DecFxArgs a; memset(&a, 0, sizeof a);
-    a.in = (const uint8_t*)d_in; a.in_bytes = 9 * n_in; a.out = d_out; a.n_units = units; a.fail = d_fail;
+    a.in = (const uint8_t*)d_in; a.in_bytes = 9 * n_in; a.out = d_out; a.n_units = units; a.fail = d_fail; a.roots = d_roots[ki];
     a.tab = d_fxtab; a.lut = d_synd_lut[ki]; a.lut_bytes = synd_lut_bytes[ki];
     a.k = (uint32_t)k; a.nb = 52; a.TS = 9u * 52u * (uint32_t)k; a.n_sym = (uint32_t)L.n_sym; a.hdr_syms = L.header_syms;
     uint64_t maxb = 0;

@@ -167,33 +167,52 @@ __device__ __forceinline__ uint32_t crc_shift(const uint32_t* zpow, uint32_t x, 
     return x;
 }
 
+// One lane = one chunk, taken as two halves in lockstep (two independent register chains), a 32-bit word per step and
+// chain by slicing-by-4: four independent table reads instead of four dependent ones.  The four 256-entry tables sit in
+// LDS in four copies each (copy = lane & 3).  Measured alternatives (8K frame, 187 MB): one dependent byte-table chain per
+// lane 147 us; this kernel 127 us; byte table in 32 per-bank copies with four chains 175 us; a coalesced row sweep with
+// advance tables 193 us (profiles/r01/notes.md).
+__device__ __forceinline__ uint32_t crc_word(const uint32_t* tb, uint32_t cp, uint32_t r, uint32_t w) {
+    r ^= w;
+    return tb[((3u * 256u + (r & 0xFFu)) << 2) + cp] ^ tb[((2u * 256u + ((r >> 8) & 0xFFu)) << 2) + cp] ^
+           tb[((1u * 256u + ((r >> 16) & 0xFFu)) << 2) + cp] ^ tb[((r >> 24) << 2) + cp];
+}
 __global__ __launch_bounds__(256) void crc_chunks_kernel(const CrcArgs a) {
-    __shared__ uint32_t tbl[256]; __shared__ uint32_t zp[kCrcPows * 32];
-    { uint32_t c = threadIdx.x; for (int j = 0; j < 8; ++j) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1); tbl[threadIdx.x] = c; }
+    __shared__ uint32_t tb[4 * 256 * 4]; __shared__ uint32_t zp[kCrcPows * 32];
+    {   // T_0[e] = the byte table; T_{j+1}[e] = T_j[e] advanced by one more zero byte (eight bit steps)
+        uint32_t c = threadIdx.x;
+        for (int j = 0; j < 4; ++j) {
+            for (int i = 0; i < 8; ++i) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+            for (int cp = 0; cp < 4; ++cp) tb[((j * 256 + threadIdx.x) << 2) + cp] = c;
+        }
+    }
     for (int i = threadIdx.x; i < kCrcPows * 32; i += blockDim.x) zp[i] = a.zpow[i];
     __syncthreads();
-    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t sum = 0;
+    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x, cp = threadIdx.x & 3u;
+    uint32_t sum = 0, part = 0;
     if (ch < a.n_chunks) {
         const uint64_t beg = (uint64_t)ch * a.chunk_bytes, end = min(beg + a.chunk_bytes, a.n_bytes);
-        uint32_t r = 0;
-        uint64_t i = beg;                                          // chunk starts are 16-B aligned (2304 = 144 * 16)
-        for (; (((uintptr_t)a.data & 15u) == 0) && i + 16 <= end; i += 16) {
-            const uint4 q = *(const uint4*)(a.data + i);
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        const uint64_t mid = min(beg + (uint64_t)(a.chunk_bytes / 32u) * 16u, end);   // halves start 16-byte aligned
+        uint32_t rA = 0, rB = 0;
+        uint64_t i = beg, j = mid;
+        if (((uintptr_t)a.data & 15u) == 0) {
+            for (; i + 16 <= mid && j + 16 <= end; i += 16, j += 16) {
+                const uint4 qa = *(const uint4*)(a.data + i), qb = *(const uint4*)(a.data + j);
+                const uint32_t wa[4] = {qa.x, qa.y, qa.z, qa.w}, wb[4] = {qb.x, qb.y, qb.z, qb.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                sum += (w[j] & 0xFFu) + ((w[j] >> 8) & 0xFFu) + ((w[j] >> 16) & 0xFFu) + (w[j] >> 24);
-                r ^= w[j];                                         // four table steps on the xor-ed word (little endian)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) r = tbl[r & 0xFFu] ^ (r >> 8);
+                for (int k = 0; k < 4; ++k) {
+                    sum = __builtin_amdgcn_sad_u8(wa[k], 0u, sum); sum = __builtin_amdgcn_sad_u8(wb[k], 0u, sum);
+                    rA = crc_word(tb, cp, rA, wa[k]); rB = crc_word(tb, cp, rB, wb[k]);
+                }
             }
         }
-        for (; i < end; ++i) { const uint32_t v = a.data[i]; sum += v; r = tbl[(r ^ v) & 0xFFu] ^ (r >> 8); }
-        atomicXor(a.chunk_crc, crc_shift(zp, r, a.n_bytes - end));   // move it to the end of the stream
+        for (; i < mid; ++i) { const uint32_t v = a.data[i]; sum += v; rA = tb[((rA ^ v) & 0xFFu) << 2] ^ (rA >> 8); }
+        for (; j < end; ++j) { const uint32_t v = a.data[j]; sum += v; rB = tb[((rB ^ v) & 0xFFu) << 2] ^ (rB >> 8); }
+        const uint32_t r = crc_shift(zp, rA, end - mid) ^ rB;
+        part = crc_shift(zp, r, a.n_bytes - end);                    // move it to the end of the stream
     }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
-    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(a.sym_sum, sum);
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_down(sum, o); part ^= __shfl_down(part, o); }
+    if ((threadIdx.x & 63) == 0) { if (part) atomicXor(a.chunk_crc, part); if (sum) atomicAdd(a.sym_sum, sum); }
 }
 
 __global__ void frame_record_kernel(const CrcArgs a, const uint8_t* words, uint64_t n_words, uint64_t frame_idx, uint32_t profile, uint32_t mode, void* recv) {

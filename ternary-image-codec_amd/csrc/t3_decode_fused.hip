@@ -42,16 +42,13 @@ __device__ __forceinline__ uint32_t d3(uint32_t x)  { return __umul24(x, 171u) >
 __device__ __forceinline__ uint32_t d9(uint32_t x)  { return __umul24(x, 228u) >> 11; }
 __device__ __forceinline__ uint32_t d27(uint32_t x) { return __umul24(x, 152u) >> 12; }
 
-// alpha^i, the field's antilog table (checked against the host field at init: t3_api_decode.cpp)
-__device__ constexpr uint8_t kExp[26] = {1, 3, 9, 5, 15, 23, 13, 17, 20, 4, 12, 14, 11, 2, 6, 18, 7, 21, 16, 26, 22, 10, 8, 24, 25, 19};
-
 struct Fix { uint32_t np; uint32_t pos[4]; uint32_t mag[4]; };   // up to t = 4 corrections (RS(26,18))
 
 // decode_block after the syndromes (OLD:567-659), FIXED flavour, for R syndromes and T = R/2.  Polynomials live in fixed
 // zero-padded registers, which is equivalent to the reference's growing vectors (only coefficient VALUES matter once the
 // Horner loops start at the true degree).  Returns false for an uncorrectable block.
 template <int R>
-__device__ __forceinline__ bool fx_correct(const uint32_t* S, Fix& fx) {
+__device__ __forceinline__ bool fx_correct(const uint32_t* S, Fix& fx, const uint32_t* __restrict__ root_tbl) {
     constexpr int T = R / 2, NP = R + 2;
     uint32_t sg[NP], bx[NP];                                        // sigma, and x^m * B (B shifted as the reference's xmdB)
 #pragma unroll
@@ -83,17 +80,16 @@ __device__ __forceinline__ bool fx_correct(const uint32_t* S, Fix& fx) {
 #pragma unroll
     for (int i = 1; i < NP; ++i) if (sg[i] != 0) deg = (uint32_t)i;
     fx.np = 0;
+#ifdef T3_ABL_DEC_BM_ONLY
+    fx.np = 1; fx.pos[0] = deg; fx.mag[0] = sg[1]; return true;
+#endif
     if (deg > (uint32_t)T) return false;                                      // then #roots > t or #roots != deg (OLD:624 + FIXED rule)
-    // Chien (OLD:611-623): sigma(alpha^-i) for the 26 positions, Horner from degree T (leading zeros are harmless)
-    uint32_t roots = 0;
+    // Chien (OLD:611-623), tabulated: sigma_0 = 1, so the T higher coefficients index the mask of the positions i with
+    // sigma(alpha^-i) = 0 (built on the host from the same Horner evaluation, t3_api_decode.cpp)
+    uint32_t ridx = sg[T];
 #pragma unroll
-    for (int i = 0; i < 26; ++i) {
-        const uint32_t x = kExp[i == 0 ? 0 : 26 - i];
-        uint32_t acc = sg[T];
-#pragma unroll
-        for (int q = T - 1; q >= 0; --q) acc = gfa(gfm(acc, x), sg[q]);
-        roots |= (acc == 0 ? 1u : 0u) << i;
-    }
+    for (int q = T - 1; q >= 1; --q) ridx = ridx * 27u + sg[q];
+    const uint32_t roots = root_tbl[ridx];
     const uint32_t np = (uint32_t)__popc(roots);
     if (np != deg) return false;
     // Omega = S(x) sigma(x) mod x^R (OLD:606-610), sigma' in characteristic 3 (OLD:625-641): sigma1 + 2 sigma2 x (+ 4th, 5th for R=8)
@@ -224,9 +220,13 @@ __global__ __launch_bounds__(640, 5) void decode_fixed_kernel(const DecFxArgs a)
                 const uint32_t yb = a.y_off + b + 9u * K * m;
 #pragma unroll
                 for (uint32_t p = 0; p < K; ++p) lds[yb + 9u * p] = (uint8_t)(d8[p] >> 3);
+#ifdef T3_ABL_DEC_NO_CORRECT
+                if (any == 0x7FFFFFFFu) {
+#else
                 if (any != 0) {                                                   // OLD:562: all-zero syndromes -> nothing to do
+#endif
                     Fix fx;
-                    if (!fx_correct<R>(S, fx)) atomicAdd(a.fail, 1u);
+                    if (!fx_correct<R>(S, fx, a.roots)) atomicAdd(a.fail, 1u);
                     else {
 #pragma unroll
                         for (int e = 0; e < R / 2; ++e)
