@@ -26,6 +26,7 @@ uint32_t* d_zpow = nullptr;     // CRC "append 2^j zero bytes" operators
 uint32_t* d_crc_acc = nullptr;  // [0] xor accumulator, [1] symbol sum
 FxTables* d_fxtab = nullptr;    // field tables of the fused FIXED decoder
 uint32_t* d_synd_lut[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t synd_lut_bytes[4] = {0, 0, 0, 0};   // per k index
+uint8_t* d_fma = nullptr;       // fma[x][y][a] = a + x y: one table read per multiply-accumulate of the corrector
 uint32_t* d_roots[4] = {nullptr, nullptr, nullptr, nullptr};   // per k index: the Chien search (OLD:611-623) of every locator, tabulated
 
 int k_index(int k) { return k == 24 ? 0 : k == 22 ? 1 : k == 20 ? 2 : k == 18 ? 3 : -1; }
@@ -62,6 +63,12 @@ int decode_fixed_fused(const void* d_in, uint64_t n_in, const t3_cfg& cfg, const
         HIPCHK(hipMalloc((void**)&d_roots[ki], n * 4));
         HIPCHK(hipMemcpy(d_roots[ki], tbl.data(), n * 4, hipMemcpyHostToDevice));
     }
+    if (!d_fma) {
+        const Field& F = field();
+        std::vector<uint8_t> t(19696, 0);
+        for (int x = 0; x < 27; ++x) for (int y = 0; y < 27; ++y) for (int c = 0; c < 27; ++c) t[(size_t)(x * 27 + y) * 27 + c] = F.t.add[c * 27 + F.t.mul[x * 27 + y]];
+        HIPCHK(hipMalloc((void**)&d_fma, t.size())); HIPCHK(hipMemcpy(d_fma, t.data(), t.size(), hipMemcpyHostToDevice));
+    }
     DecFxArgs a; memset(&a, 0, sizeof a);
     a.in = (const uint8_t*)d_in; a.in_bytes = 9 * n_in; a.out = d_out; a.n_units = units; a.fail = d_fail; a.roots = d_roots[ki];
     a.tab = d_fxtab; a.lut = d_synd_lut[ki]; a.lut_bytes = synd_lut_bytes[ki];
@@ -70,7 +77,8 @@ int decode_fixed_fused(const void* d_in, uint64_t n_in, const t3_cfg& cfg, const
     for (int b = 0; b < 9; ++b) { a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b]; a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6); maxb = std::max<uint64_t>(maxb, L.band_blocks[b]); }
     a.n_tiles = (uint32_t)((maxb + a.nb - 1) / a.nb);
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
-    a.y_off = (kFxLut + a.lut_bytes + 15u) & ~15u;
+    a.fma = d_fma; a.fma_off = (kFxLut + a.lut_bytes + 15u) & ~15u;
+    a.y_off = a.fma_off + 19696u;
     a.o_off = (a.y_off + a.TS + 16u + 15u) & ~15u;
     a.lds_bytes = a.o_off + (to_pixels ? (a.TS / 13u) * 18u : (a.TS / 26u) * 27u) + 64u;
     const void* fn = nullptr;
@@ -84,12 +92,12 @@ int decode_fixed_fused(const void* d_in, uint64_t n_in, const t3_cfg& cfg, const
     auto it = occ.find(fn);
     if (it == occ.end()) {
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        int o = 1; HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, 576, a.lds_bytes));
+        int o = 1; HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, 512, a.lds_bytes));
         it = occ.emplace(fn, std::max(1, o)).first;
     }
     const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(a.n_tiles, (uint32_t)(api_n_cu() * it->second)));
     void* args[] = {(void*)&a};
-    HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(576), args, a.lds_bytes, s));
+    HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(512), args, a.lds_bytes, s));
     return T3_OK;
 }
 

@@ -55,6 +55,7 @@ struct DecFxArgs {
     void* out; uint64_t n_units;               // pixels (to_pixels) or words to emit
     uint32_t* fail;
     const FxTables* tab; const uint32_t* lut; uint32_t lut_bytes;
+    const uint8_t* fma; uint32_t fma_off;      // [27][27][27]: fma[x][y][a] = a + x y in GF(27) (19683 bytes), and its LDS offset
     const uint32_t* roots;                     // [27^t]: bit i set <=> 1 + s1 x + .. + st x^t vanishes at alpha^-i, index s1 + 27 s2 + ..
     uint32_t k, nb, n_tiles, TS;               // nb blocks per band per tile (multiple of 13), TS = 9*nb*k stream symbols
     uint32_t n_sym;                            // real stream symbols (the rest of the last blocks is zero padding)

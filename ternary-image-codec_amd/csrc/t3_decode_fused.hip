@@ -48,7 +48,8 @@ struct Fix { uint32_t np; uint32_t pos[4]; uint32_t mag[4]; };   // up to t = 4 
 // zero-padded registers, which is equivalent to the reference's growing vectors (only coefficient VALUES matter once the
 // Horner loops start at the true degree).  Returns false for an uncorrectable block.
 template <int R>
-__device__ __forceinline__ bool fx_correct(const uint32_t* S, Fix& fx, const uint32_t* __restrict__ root_tbl) {
+__device__ __forceinline__ bool fx_correct(const uint32_t* S, Fix& fx, const uint32_t* __restrict__ root_tbl, uint32_t FMA) {
+    auto fma = [FMA](uint32_t acc, uint32_t x, uint32_t y) -> uint32_t { return lds[FMA + (x * 27u + y) * 27u + acc]; };   // acc + x y
     constexpr int T = R / 2, NP = R + 2;
     uint32_t sg[NP], bx[NP];                                        // sigma, and x^m * B (B shifted as the reference's xmdB)
 #pragma unroll
@@ -59,15 +60,15 @@ __device__ __forceinline__ bool fx_correct(const uint32_t* S, Fix& fx, const uin
     for (int n = 0; n < R; ++n) {
         uint32_t d = S[n];
 #pragma unroll
-        for (int i = 1; i <= n; ++i) d = gfa(d, gfm(sg[i], S[n - i]));      // sigma[i] = 0 beyond L: same sum as OLD:572
+        for (int i = 1; i <= n; ++i) d = fma(d, sg[i], S[n - i]);           // sigma[i] = 0 beyond L: same sum as OLD:572
         const bool upd = d != 0 && 2u * L <= (uint32_t)n;
-        const uint32_t iv = lds[INV + d];
+        const uint32_t iv = lds[INV + d], nd = lds[NEG + d];
         uint32_t nb[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             if (i <= n + 1) {
                 const uint32_t old = sg[i];
-                sg[i] = gfs(old, gfm(d, bx[i]));                             // d == 0: product 0, unchanged (OLD:573-587)
+                sg[i] = fma(old, nd, bx[i]);                                 // old - d bx; d == 0: unchanged (OLD:573-587)
                 nb[i] = gfm(old, iv);                                        // T * inv(delta) (OLD:590-592)
             } else nb[i] = 0;
         }
@@ -98,7 +99,7 @@ __device__ __forceinline__ bool fx_correct(const uint32_t* S, Fix& fx, const uin
     for (int q = 0; q < R; ++q) {
         uint32_t acc = S[q];                                                   // j = 0 term, sigma0 = 1
 #pragma unroll
-        for (int j = 1; j <= T; ++j) if (j <= q) acc = gfa(acc, gfm(S[q - j], sg[j]));
+        for (int j = 1; j <= T; ++j) if (j <= q) acc = fma(acc, S[q - j], sg[j]);
         Om[q] = acc;
     }
     uint32_t r = roots;
@@ -109,9 +110,9 @@ __device__ __forceinline__ bool fx_correct(const uint32_t* S, Fix& fx, const uin
             const uint32_t xi = lds[EXP + (p == 0 ? 0u : 26u - p)];
             uint32_t num = Om[R - 1];
 #pragma unroll
-            for (int q = R - 2; q >= 0; --q) num = gfa(gfm(num, xi), Om[q]);
-            uint32_t den = gfa(sg[1], gfm(gfa(sg[2], sg[2]), xi));             // sigma1 + 2 sigma2 x  (x^2 term of sigma' is 3 sigma3 = 0)
-            if constexpr (T >= 4) den = gfa(den, gfm(gfm(gfm(sg[4], xi), xi), xi));   // + 4 sigma4 x^3 = sigma4 x^3
+            for (int q = R - 2; q >= 0; --q) num = fma(Om[q], num, xi);
+            uint32_t den = fma(sg[1], gfa(sg[2], sg[2]), xi);                  // sigma1 + 2 sigma2 x  (x^2 term of sigma' is 3 sigma3 = 0)
+            if constexpr (T >= 4) den = fma(den, gfm(gfm(sg[4], xi), xi), xi);  // + 4 sigma4 x^3 = sigma4 x^3
             if (den == 0) return false;                                        // OLD:656
             fx.pos[e] = p; fx.mag[e] = gfm(lds[NEG + num], lds[INV + den]);    // OLD:657; FIXED subtracts it
         }
@@ -130,7 +131,7 @@ __device__ __forceinline__ Row row(uint32_t b) { return *(const Row*)(lds + 16u 
 }  // namespace
 
 template <int R, bool TO_PIXELS>
-__global__ __launch_bounds__(640, 5) void decode_fixed_kernel(const DecFxArgs a) {
+__global__ __launch_bounds__(512, 4) void decode_fixed_kernel(const DecFxArgs a) {
     constexpr uint32_t K = 26 - R, SLAB = R == 8 ? 768u : 512u;
     const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // constants -> LDS
@@ -140,16 +141,17 @@ __global__ __launch_bounds__(640, 5) void decode_fixed_kernel(const DecFxArgs a)
     }
     for (uint32_t i = tid * 16u; i < (uint32_t)sizeof(FxTables); i += nthr * 16u) *(uint4*)(lds + kFxTab + i) = *(const uint4*)((const uint8_t*)a.tab + i);
     for (uint32_t i = tid * 16u; i < a.lut_bytes; i += nthr * 16u) *(uint4*)(lds + kFxLut + i) = *(const uint4*)((const uint8_t*)a.lut + i);
+    for (uint32_t i = tid * 16u; i < 19696u; i += nthr * 16u) *(uint4*)(lds + a.fma_off + i) = *(const uint4*)(a.fma + i);
     __syncthreads();
 
     const uint32_t units_tile = TO_PIXELS ? (a.TS / 13u) * 3u : (a.TS / 26u) * 3u;       // pixels / words produced per tile
     for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         // ---------------- D1-D4: one lane = one block of band `wave` ----------------
-        if (wave < 9u) {
-            const uint32_t b = wave, m = lane;
+        {
+            const uint32_t item = tid, b = min(item / a.nb, 8u), m = item - b * a.nb;   // one lane = one block, dealt linearly across the bands
             const Row rw = row(b);
             const uint64_t mg = (uint64_t)tile * a.nb + m;
-            if (m < a.nb && mg < rw.blocks) {
+            if (item < 9u * a.nb && mg < rw.blocks) {
                 const uint8_t* g = a.in + a.hdr_syms + rw.body_off + 26ull * mg;
                 const uint32_t sh = ((uint32_t)(uintptr_t)g & 3u) * 8u;
                 uint32_t w[7];
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(640, 5) void decode_fixed_kernel(const DecFxArgs a)
                 if (any != 0) {                                                   // OLD:562: all-zero syndromes -> nothing to do
 #endif
                     Fix fx;
-                    if (!fx_correct<R>(S, fx, a.roots)) atomicAdd(a.fail, 1u);
+                    if (!fx_correct<R>(S, fx, a.roots, a.fma_off)) atomicAdd(a.fail, 1u);
                     else {
 #pragma unroll
                         for (int e = 0; e < R / 2; ++e)
