@@ -177,10 +177,17 @@ def main():
                    "frame_px": NPX, "coded_words": n_enc, "sharding": "frames per rank, no data-path collective; one all-gather of index records per batch"},
         "encode_ms": round(enc_avg, 4), "decode_ms": round(dec_avg, 4),
         "encode_mpix_s": round(NPX / enc_avg / 1e3, 1), "decode_mpix_s": round(NPX / dec_avg / 1e3, 1),
-        "roofline": {"kernel": "encode_kernel<FE_PIXELS>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"kernel": "encode_kernel_k<FE_PIXELS, 1-D, r=6>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                     "launch_ms": round(enc_avg, 4)},
+                     "launch_ms": round(enc_avg, 4),
+                     "note": "north-star kernel (SURVEY 8d); a plain device copy of the same volume (profiles/copy_ceiling.py) reaches 5.19 TB/s = 0.65 of peak on this part"},
     }
+    if not args.encode_only:      # the decoder is the longer kernel of the step: same definition, SURVEY 8d decode bytes + 6 B/px
+        dec_bytes = 9 * n_fenc + 6 * NPX
+        out["roofline_decode"] = {"kernel": "decode_fixed_kernel<r=6, to_pixels> (+ header read-back and failure-flag sync of the synchronous entry point)",
+                                  "bound": "hbm", "achieved": round(dec_bytes / (dec_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(dec_bytes / (dec_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                  "algorithmic_bytes_per_launch": dec_bytes, "launch_ms": round(dec_avg, 4)}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(orc, ol, px)
     print(json.dumps(out))
