@@ -129,7 +129,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
             waves = (blocks_total + 63) / 64;                          // lanes are dealt to blocks linearly across bands
             if (waves > (pass == 0 ? 8u : (uint32_t)kMaxWaves)) break;   // pass 0: 512-thread workgroups, three per CU
             const uint32_t groups = (uint32_t)(9 * Lq / GS) + 6, stage = groups * GB + 1024 + 32;   // +1 KiB: LDS-DMA pieces are whole
-            const uint32_t total = kLdsHdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq)) + kSymBack + round16(stage);
+            const uint32_t total = kLdsHdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq)) + kSymBack + (L.interleave2d ? 1u : 2u) * round16(stage);
             (void)outb;
             if (total > budget) break;
             // wave-instructions per stream symbol: phase 2 costs ~180 per wave, phase 1 (pixels) ~120 per wave-iteration
@@ -161,7 +161,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     a.n_items = nw; a.n_tiles = n_tiles;
     { uint32_t acc = 0; for (int b = 0; b < 9; ++b) { a.band_first[b] = acc; acc += a.band_nb_tile[b]; } a.band_first[9] = acc; }
     a.stage_stride = round16(a.stage_groups * GB + 1024 + 32);
-    a.lds_bytes = a.stage_off + a.stage_stride;
+    a.lds_bytes = a.stage_off + (L.interleave2d ? 1u : 2u) * a.stage_stride;   // 1-D: two stage buffers (the next tile streams in early)
     a.n_sym = (uint32_t)L.n_sym;
     const ScrCycle sc = scrambler_cycle(cfg.seed_a, cfg.seed_b, cfg.seed_s0);
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];

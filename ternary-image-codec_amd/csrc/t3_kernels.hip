@@ -699,33 +699,39 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     const bool dyn = !IL && a.tile_ctr != nullptr;
     const uint32_t NC = a.n_classes, cls = blockIdx.x % NC;
     uint32_t* const ctr = a.tile_ctr + 64u * cls;                              // one counter per class, 256 B apart
-    const uint32_t j0 = (gridDim.x - cls + NC - 1u) / NC;                      // workgroups in this class = first ticketed index
-    uint32_t pend = 0;                                                         // thread 0: ticket of the tile after the next one
+    const uint32_t wgc = (gridDim.x - cls + NC - 1u) / NC;                     // workgroups in this class
+    // a class's tiles are cls + NC j: j < wgc first tiles (= blockIdx), wgc <= j < 2 wgc second tiles (static too), then tickets
+    uint32_t pend = 0;                                                         // thread 0: ticket of the tile two after the current one
     if (dyn && tid == 0) pend = atomicAdd(ctr, 1u);
-    for (uint32_t tile = blockIdx.x, nxt = 0; tile < a.n_tiles; tile = nxt) {
+    // the input of tile i+1 is requested at the top of tile i into the other stage buffer, by the waves that phase 1 (pixels)
+    // leaves idle: issuing the LDS-DMA costs ~400 cycles per KiB piece and would otherwise sit between the two phases
+    const uint32_t w0 = FE == FE_PIXELS ? min(a.p1_wpp, nwv - 1u) : 0u;
+    uint32_t par = 0;
+    for (uint32_t tile = blockIdx.x, nxt = dyn ? cls + NC * (wgc + blockIdx.x / NC) : blockIdx.x + gridDim.x, nn = 0; tile < a.n_tiles; tile = nxt, nxt = nn, par ^= 1u) {
         const uint32_t S0 = tile * TS;
-        const uint32_t stage = a.stage_off;
+        const uint32_t stage = a.stage_off + (IL ? 0u : par * a.stage_stride);
         // ---------------- phase 1: input -> stream-ordered symbols in LDS ----------------
         if constexpr (!IL) {
             barrier_input(younger);                                           // this tile's input has landed, everyone left phase 2
             T3_STAMP(0);
             uint32_t ticket = 0;
-            if (dyn && tid == 0) ticket = atomicAdd(ctr, 1u);                 // drawn two tiles ahead: its latency hides under a whole tile
+            if (dyn && tid == 0) ticket = atomicAdd(ctr, 1u);                 // drawn three tiles ahead: its latency hides under a whole tile
+#ifndef T3_ABL_NO_PREFETCH
+            if (nxt < a.n_tiles && wave >= w0)
+                stage_input<FE>(a, a.stage_off + (par ^ 1u) * a.stage_stride, first_group(nxt * TS), (nxt * TS + TS + GS - 1u) / GS, lane, wave - w0, nwv - w0);
+#endif
+            T3_STAMP(4);
 #ifndef T3_ABL_NO_P1
             if constexpr (FE == FE_PIXELS) convert_pixels_packed<(1 << SH)>(a, stage, ((uint64_t)first_group(S0) * kGroupBytes) & ~15ull, S0, TS, lane, wave, nwv);
             else convert_groups<FE, false, SH>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, tid, nthr);
 #endif
             T3_STAMP(5);                                                      // (diagnostic) this wave's conversion
-            if (dyn && tid == 0) { *(uint32_t*)(lds + 328) = cls + NC * (j0 + pend); pend = ticket; }
-            barrier_lds();                                                    // symbols complete; the stage buffer is free again
+            if (dyn && tid == 0) { *(uint32_t*)(lds + 328) = cls + NC * (2u * wgc + pend); pend = ticket; }
+            barrier_lds();                                                    // symbols complete
             T3_STAMP(1);
-            nxt = dyn ? __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + 328)) : tile + gridDim.x;   // its input streams in under phase 2
-#ifndef T3_ABL_NO_PREFETCH
-            if (nxt < a.n_tiles) stage_input<FE>(a, stage, first_group(nxt * TS), (nxt * TS + TS + GS - 1u) / GS, lane, wave, nwv);
-#endif
-            T3_STAMP(4);
+            nn = dyn ? __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + 328)) : nxt + gridDim.x;   // the tile after the next one
         } else {
-            nxt = tile + gridDim.x;
+            nn = nxt + gridDim.x;
             __syncthreads();                                                  // everyone left phase 2 of the previous tile
             for (uint32_t i = tid * 16u; i < TS; i += nthr * 16u) *(uint4*)(lds + a.sym_off + i) = make_uint4(0, 0, 0, 0);
             uint32_t u_lo = S0, u_hi = S0;                                   // pre-interleave symbols this tile needs: whole row segments
