@@ -155,10 +155,13 @@ int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_r
 int read_header(const void* d_in, uint64_t n_in, int mode, t3_cfg* seen, uint64_t* n_raw, uint8_t next[3], hipStream_t s) {
     const uint64_t hw = mode == T3_MODE_FIXED ? 10 : 6;
     if (n_in < hw) return T3_E_HEADER;                                     // OLD:920
-    uint8_t h[96];
+    // pinned mailbox: the 54/90 header bytes come back by a real asynchronous DMA (a pageable target costs a staging copy)
+    static uint8_t* h = nullptr;
+    if (!h) HIPCHK(hipHostMalloc((void**)&h, 128, hipHostMallocDefault));
     HIPCHK(hipMemcpyAsync(h, d_in, hw * 9, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    return header_parse(h, n_in, mode, *seen, n_raw, next);
+    uint8_t hb[96]; memcpy(hb, h, hw * 9);
+    return header_parse(hb, n_in, mode, *seen, n_raw, next);
 }
 }  // namespace
 
@@ -222,14 +225,18 @@ int t3hip_decode_profile_dev(const void* d_in, uint64_t n_in, t3_cfg* seen, void
     uint64_t n_raw = 0; uint8_t next[3];
     int rc = read_header(d_in, n_in, seen->mode, seen, &n_raw, next, s);
     if (rc) return rc;
-    uint32_t* flag = api_flag();
-    HIPCHK(hipMemsetAsync(flag, 0, 4, s));
-    rc = decode_body(d_in, n_in, *seen, n_raw, next, d_out, cap, n_out, to_pixels, flag, s);
+    // failure counter in mapped pinned host memory: written only by lanes that give up on a block, read after the sync
+    // without a copy (the previous synchronous call has drained, so the host may clear it directly)
+    static uint32_t* h_flag = nullptr; static uint32_t* d_flag_map = nullptr;
+    if (!h_flag) {
+        HIPCHK(hipHostMalloc((void**)&h_flag, 64, hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void**)&d_flag_map, h_flag, 0));
+    }
+    *(volatile uint32_t*)h_flag = 0;
+    rc = decode_body(d_in, n_in, *seen, n_raw, next, d_out, cap, n_out, to_pixels, d_flag_map, s);
     if (rc) { if (rc != T3_E_CAPACITY) *n_out = 0; return rc; }
-    uint32_t nfail = 0;
-    HIPCHK(hipMemcpyAsync(&nfail, flag, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (nfail) { *n_out = 0; return T3_E_RS; }                                // OLD:987,1017: false, out stays empty
+    if (*(volatile uint32_t*)h_flag) { *n_out = 0; return T3_E_RS; }           // OLD:987,1017: false, out stays empty
     return T3_OK;
 }
 

@@ -307,51 +307,56 @@ __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t tile,
     constexpr uint32_t TB = kLdsHdr, MB = kLdsHdr + kMfmaModOff;
     const uint32_t n = lane & 31u, h = lane >> 5;
     const uint32_t tb3 = __builtin_amdgcn_readfirstlane((tile * a.nb_uniform) % 3u);
-    uint32_t issued = 0;
-#pragma unroll
-    for (uint32_t set = 0; set < 2; ++set) {                                  // a wave does two sets of 32 blocks
+    // A wave does two sets of 32 blocks.  The table reads of BOTH sets are issued before either set's MFMA chain, so the
+    // second set's two dependent LDS round trips hide under the first set's chain and epilogue.
+    struct Set { v4i Bv[3]; uint32_t W[3]; uint32_t c0, mg; uint64_t goff; bool valid, first; uint32_t dd0, dd1; };
+    auto load = [&](uint32_t set, Set& s) {
         const uint32_t item = wave * 64u + set * 32u + n;                     // blocks are dealt linearly across the bands
         const uint32_t b = min(fdiv(item, a.div_nb), 8u), m = item - b * a.nb_uniform;
         const BandRow r = band_row(b);
-        const uint32_t mg = tile * a.nb_uniform + m;
-        const bool valid = item < a.n_items && mg < r.blocks;
-        if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;               // wave-uniform
+        s.mg = tile * a.nb_uniform + m;
+        s.valid = item < a.n_items && s.mg < r.blocks;                        // lanes without a block run along (reads stay inside LDS) and store nothing
+        s.goff = r.body_off + 26ull * s.mg;
+        s.first = r.body_off == 0 && s.mg == 0 && h == 0;
         // scrambler phase of the block's first symbol: (boff6 + 2 (mg mod 3)) mod 6 (26 == 2 mod 6), without wide multiplies
         uint32_t m3 = tb3 + m - 3u * ((m * 683u) >> 11); m3 -= m3 >= 3u ? 3u : 0u;   // m < 2048
         uint32_t c0 = r.boff6 + 2u * m3; c0 -= c0 >= 6u ? 6u : 0u;
+        s.c0 = c0;
         uint32_t c0h = c0 + 4u * h; c0h -= c0h >= 6u ? 6u : 0u;               // ... of this lane's first position 4h
         const uint32_t cycs = a.cyc24 >> (2u * c0h);
         uint32_t vb[6];                                                       // table base per position class: state (4 KiB apart), own bank copy
 #pragma unroll
         for (uint32_t q = 0; q < 6; ++q) vb[q] = (((cycs >> (2u * q)) & 3u) << 12) | (TB + 4u * n);
         const uint32_t sa = a.sym_off + b + 9u * K * m + 36u * h;
-        v4i Bv[3]; uint32_t W[3]; uint32_t dd0 = 0, dd1 = 0;
+        s.dd0 = 0; s.dd1 = 0;
 #pragma unroll
-        for (uint32_t s = 0; s < 3; ++s) {
+        for (uint32_t st = 0; st < 3; ++st) {
             uint32_t x[4];
 #pragma unroll
             for (uint32_t d = 0; d < 4; ++d) {
-                const uint32_t d4 = lds_u8(sa + 72u * s + 9u * d);            // positions >= k read neighbouring bytes: they meet zero matrix columns
-                if (s == 0 && d == 0) dd0 = d4;
-                if (s == 0 && d == 1) dd1 = d4;
-                x[d] = lds_u32((d4 << 5) + vb[(8u * s + d) % 6u]);
-                Bv[s][d] = (int)x[d];
+                const uint32_t d4 = lds_u8(sa + 72u * st + 9u * d);           // positions >= k read neighbouring bytes: they meet zero matrix columns
+                if (set == 0 && st == 0 && d == 0) s.dd0 = d4;                // (body symbols 0 and 1 sit in set 0 of wave 0)
+                if (set == 0 && st == 0 && d == 1) s.dd1 = d4;
+                x[d] = lds_u32((d4 << 5) + vb[(8u * st + d) % 6u]);
+                s.Bv[st][d] = (int)x[d];
             }
             const uint32_t t01 = __builtin_amdgcn_perm(x[1], x[0], 0x0c0c0703u), t23 = __builtin_amdgcn_perm(x[3], x[2], 0x07030c0cu);
-            W[s] = t01 | t23;                                                  // the four scrambled symbols
+            s.W[st] = t01 | t23;                                               // the four scrambled symbols
         }
-        uint32_t c0K = c0 + (K % 6u); c0K -= c0K >= 6u ? 6u : 0u;             // scrambler phase of the first parity symbol
+    };
+    auto finish = [&](Set& s) -> uint32_t {
+        uint32_t c0K = s.c0 + (K % 6u); c0K -= c0K >= 6u ? 6u : 0u;           // scrambler phase of the first parity symbol
         if constexpr (R >= 4) {     // the states of the parity symbols ride in unused positions of the upper half (see mfma_scr_pos)
             const u32x2 sd = *T3_LDS_PTR(u32x2, kMfmaScr + 8u * c0K);
-            if constexpr (R == 4) Bv[2][2] = h ? (int)sd.x : Bv[2][2];
-            else { Bv[2][0] = h ? (int)sd.x : Bv[2][0]; Bv[2][1] = h ? (int)sd.y : Bv[2][1]; }
+            if constexpr (R == 4) s.Bv[2][2] = h ? (int)sd.x : s.Bv[2][2];
+            else { s.Bv[2][0] = h ? (int)sd.x : s.Bv[2][0]; s.Bv[2][1] = h ? (int)sd.y : s.Bv[2][1]; }
         }
         v16i acc = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64};   // bias: trit sums in [-60, 62] -> table index
 #ifndef T3_ABL_NO_MFMA
 #pragma unroll
-        for (uint32_t s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Afr[s], Bv[s], acc, 0, 0, 0);
+        for (uint32_t st = 0; st < 3; ++st) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Afr[st], s.Bv[st], acc, 0, 0, 0);
 #else
-        acc[0] += Bv[0][0] & 1; acc[3] += Bv[1][1] & 1; acc[6] += Bv[2][2] & 1; acc[1] += (Bv[0][1] ^ Bv[0][2] ^ Bv[0][3] ^ Bv[1][0] ^ Bv[1][2] ^ Bv[1][3] ^ Bv[2][0] ^ Bv[2][1] ^ Bv[2][3]) & 1;
+        acc[0] += s.Bv[0][0] & 1; acc[3] += s.Bv[1][1] & 1; acc[6] += s.Bv[2][2] & 1; acc[1] += (s.Bv[0][1] ^ s.Bv[0][2] ^ s.Bv[0][3] ^ s.Bv[1][0] ^ s.Bv[1][2] ^ s.Bv[1][3] ^ s.Bv[2][0] ^ s.Bv[2][1] ^ s.Bv[2][3]) & 1;
 #endif
         // parity symbols of this lane: h H + jj; mod-3 fold and 3^t weight by byte tables (one bank per dword: conflict-free)
         uint32_t Pown = 0;
@@ -359,50 +364,50 @@ __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t tile,
         for (uint32_t jj = 0; jj < H; ++jj) {
             uint32_t x0 = (uint32_t)acc[3 * jj], x1 = (uint32_t)acc[3 * jj + 1], x2 = (uint32_t)acc[3 * jj + 2];
             if constexpr (R == 2) {                                              // k = 24: no free position, add the state here
-                const uint32_t st = (a.cyc24 >> (2u * (c0K + h))) & 3u;
-                x0 += st; x1 += st; x2 += st;
+                const uint32_t stt = (a.cyc24 >> (2u * (c0K + h))) & 3u;
+                x0 += stt; x1 += stt; x2 += stt;
             }
             const uint32_t sym = lds_u8(MB + x0) + lds_u8(MB + 128u + x1) + lds_u8(MB + 256u + x2);
             Pown |= sym << (8u * jj);
         }
         const uint32_t Plo = __builtin_amdgcn_permlane32_swap(Pown, Pown, false, false)[0];   // upper half: the h = 0 partner's parities
-        uint32_t W2 = W[2], tail;
+        uint32_t W2 = s.W[2], tail;
         if constexpr (R == 6)      { W2 = h ? ((Plo & 0x00FFFFFFu) | (Pown << 24)) : W2; tail = Pown >> 8; }
         else if constexpr (R == 8) { W2 = h ? ((Plo >> 16) | (Pown << 16)) : ((W2 & 0xFFFFu) | (Pown << 16)); tail = Pown >> 16; }
         else if constexpr (R == 4) { W2 = h ? ((W2 & 0xFFFFu) | (Plo << 16)) : W2; tail = Pown; }
         else                       { tail = (Plo & 0xFFu) | (Pown << 8); }
-        uint32_t W0 = W[0];
-        if (r.body_off == 0 && mg == 0 && h == 0)               // body symbols 0 and 1 see the pre-period states (exact whatever the seed; OLD:81-87)
-            W0 = (W0 & 0xFFFF0000u) | add13(dd0 >> 2, a.pre0) | (add13(dd1 >> 2, a.pre1) << 8);
+        uint32_t W0 = s.W[0];
+        if (s.first)                                            // body symbols 0 and 1 see the pre-period states (exact whatever the seed; OLD:81-87)
+            W0 = (W0 & 0xFFFF0000u) | add13(s.dd0 >> 2, a.pre0) | (add13(s.dd1 >> 2, a.pre1) << 8);
         // Lane (n, h) holds bytes [8s + 4h, +4) of block n.  Two half-wave exchanges give the lower lane bytes 0..15 and the
         // upper lane bytes 10..25 of the block: ONE 16-byte store per lane covers the 26 bytes (bytes 10..15 are written by
         // both, with the same values), instead of three scattered dwords and a short -- an eighth of the cache-line requests.
         const auto sw = __builtin_amdgcn_permlane32_swap(W0, W2, false, false);   // upper half of W0 (bytes 4..7) <-> lower half of W2 (bytes 16..19)
         const uint32_t Xa = sw[0], Xb = sw[1];                                    // h=0: Xa = bytes 0..3, Xb = 4..7;   h=1: Xa = 16..19, Xb = 20..23
-        const auto sw1 = __builtin_amdgcn_permlane32_swap(W[1], W[1], false, false);
+        const auto sw1 = __builtin_amdgcn_permlane32_swap(s.W[1], s.W[1], false, false);
         const uint32_t oW1 = h ? sw1[0] : sw1[1];                                  // the partner's W[1]: h=0 gets bytes 12..15, h=1 bytes 8..11
-        const uint32_t S0 = h ? W[1] : Xa, S1 = h ? Xa : Xb, S2 = h ? Xb : W[1];   // h=0: 0..3, 4..7, 8..11;  h=1: 12..15, 16..19, 20..23
+        const uint32_t S0 = h ? s.W[1] : Xa, S1 = h ? Xa : Xb, S2 = h ? Xb : s.W[1];   // h=0: 0..3, 4..7, 8..11;  h=1: 12..15, 16..19, 20..23
         U128a2 E;
         E.v[0] = h ? __builtin_amdgcn_alignbit(S0, oW1, 16) : S0;                  // h=1: bytes 10..13
         E.v[1] = h ? __builtin_amdgcn_alignbit(S1, S0, 16) : S1;
         E.v[2] = h ? __builtin_amdgcn_alignbit(S2, S1, 16) : S2;
         E.v[3] = h ? __builtin_amdgcn_alignbit(tail, S2, 16) : oW1;                // h=1: bytes 22..25
 #ifdef T3_ABL_NO_STORE
-        if (valid && a.n_tiles == 0xFFFFFFFFu)
+        if (s.valid && a.n_tiles == 0xFFFFFFFFu)
 #else
-        if (valid)
+        if (s.valid)
 #endif
-#if defined(T3_ABL_STORE_LOCAL)
-            *(U128a2*)(a.body_out + 26u * (item & 511u) + 10u * h + 16384u * (blockIdx.x & 1023u)) = E;   // timing only: L2-resident target
-#elif defined(T3_ABL_STORE_ALIGNED)
-            *(u32x4*)(a.body_out + ((r.body_off + 26ull * mg) & ~15ull) + 16u * h) = __builtin_bit_cast(u32x4, E);   // timing only: 16-byte aligned
-#else
-            *(U128a2*)(a.body_out + r.body_off + 26ull * mg + 10u * h) = E;        // 2-byte aligned
-#endif
+            *(U128a2*)(a.body_out + s.goff + 10u * h) = E;                         // 2-byte aligned
 #ifndef T3_ABL_NO_STORE
-        issued += 1u;
+        return __builtin_amdgcn_ballot_w64(s.valid) != 0 ? 1u : 0u;               // a store with no active lane is branched over
+#else
+        return 0u;
 #endif
-    }
+    };
+    Set s0, s1;
+    load(0, s0); load(1, s1);
+    uint32_t issued = finish(s0);
+    issued += finish(s1);
     return issued;
 }
 
