@@ -9,7 +9,8 @@ One step = one synthetic 8K (7680x4320) frame through the hot path on each rank,
      reference's b6c43f2f4aa44763),
   2. decode of the same frame's FIXED-mode (v6c) stream carrying 0..3 injected symbol errors in every RS block
      (BASELINE configs[4] semantics; exact recovery of the pixels is asserted after the timed region),
-  3. the frame's index record (CRC-32 + header symbols) for the T3V-style super-frame index.
+  3. the frame's index record (CRC-32 + header symbols) for the T3V-style super-frame index; it depends only on step 1 and
+     runs on a second HIP stream under the decode (--serial puts it back on the main stream).
 Frames are independent, so ranks shard them with no data-path collective (weak scaling); the only exchange is one
 all-gather of the K fixed-size index records per rank at the end of the batch (RCCL), inside the timed region.
 
@@ -68,6 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--encode-only", action="store_true", help="profiling aid: skip decode + index in the loop")
+    ap.add_argument("--serial", action="store_true", help="index record on the main stream instead of overlapping it with the decode")
     ap.add_argument("--no-verify", action="store_true", help="profiling aid for timing-only ablation builds (results are wrong by construction)")
     args = ap.parse_args()
 
@@ -87,7 +89,11 @@ def main():
     sf = __import__("ternary_image_codec_amd.superframe", fromlist=["x"])
     t3.init(local)
     orc = ol.oracle()
-    stream = torch.cuda.current_stream().cuda_stream
+    cur = torch.cuda.current_stream()
+    stream = cur.cuda_stream
+    # the index record (CRC-32 of the coded frame) only depends on the encode: it runs on a second HIP stream under the decode
+    s2 = None if args.serial else torch.cuda.Stream(device=torch.device("cuda", local))
+    enc_done, rec_done = torch.cuda.Event(), torch.cuda.Event()
     dev = torch.device("cuda", local)
 
     # ---- synthetic input, resident in HBM before any timing (SURVEY §8d generator; frame seed = 12345 + rank) ----
@@ -107,6 +113,8 @@ def main():
     torch.cuda.synchronize()
 
     def step(i, ev=None):
+        if s2 is not None:
+            cur.wait_event(rec_done)                        # the previous frame's record has read d_enc
         if ev is not None:
             ev[0].record(stream)
         t3.encode_frame_dev(d_px.data_ptr(), NPX, cfg, d_enc.data_ptr(), n_enc, stream)
@@ -114,12 +122,17 @@ def main():
             ev[1].record(stream)
         if args.encode_only:
             return
+        rec_args = (d_enc.data_ptr(), n_enc, i * world + rank, cfg, d_recs[i % len(d_recs)].data_ptr(), d_scr.data_ptr(), 64)
+        if s2 is not None:
+            enc_done.record(cur); s2.wait_event(enc_done)
+            t3.frame_record_dev(*rec_args, s2.cuda_stream); rec_done.record(s2)
         seen = t3.DecoderContext(mode=t3.MODE_FIXED).cfg_last_seen
         rc, n = t3.decode_profile_dev(d_fenc.data_ptr(), n_fenc, seen, d_back.data_ptr(), NPX, True, stream)
         assert args.no_verify or (rc == 0 and n == NPX), (rc, n)
         if ev is not None:
             ev[2].record(stream)
-        t3.frame_record_dev(d_enc.data_ptr(), n_enc, i * world + rank, cfg, d_recs[i % len(d_recs)].data_ptr(), d_scr.data_ptr(), 64, stream)
+        if s2 is None:
+            t3.frame_record_dev(*rec_args, stream)
 
     for i in range(args.warmup):
         step(i)
@@ -133,6 +146,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, events[i])
+    if s2 is not None:
+        cur.wait_stream(s2)
     if world > 1 and not args.encode_only:
         gathered = sf.gather_records(d_recs)               # the one exchange step: super-frame index records (RCCL all-gather)
     torch.cuda.synchronize()
