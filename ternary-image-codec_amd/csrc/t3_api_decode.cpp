@@ -80,7 +80,7 @@ int decode_fixed_fused(const void* d_in, uint64_t n_in, const t3_cfg& cfg, const
     a.fma = d_fma; a.fma_off = (kFxLut + a.lut_bytes + 15u) & ~15u;
     a.y_off = a.fma_off + 19696u;
     a.o_off = (a.y_off + a.TS + 16u + 15u) & ~15u;
-    a.lds_bytes = a.o_off + (to_pixels ? (a.TS / 13u) * 18u : (a.TS / 26u) * 27u) + 64u;
+    a.lds_bytes = a.o_off + (to_pixels ? 0u : (a.TS / 26u) * 27u) + 64u;      // pixels are stored straight from registers
     const void* fn = nullptr;
     switch (26 - k) {
         case 2: fn = to_pixels ? (const void*)decode_fixed_kernel<2, true> : (const void*)decode_fixed_kernel<2, false>; break;

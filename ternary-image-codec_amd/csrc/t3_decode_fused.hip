@@ -242,23 +242,57 @@ __global__ __launch_bounds__(512, 4) void decode_fixed_kernel(const DecFxArgs a)
         const uint64_t unit0 = (uint64_t)tile * units_tile;
         const uint32_t n_here = (uint32_t)min((uint64_t)units_tile, a.n_units > unit0 ? a.n_units - unit0 : 0ull);
         if constexpr (TO_PIXELS) {
-            const uint32_t ntr = a.TS / 13u;                                       // triples in the tile
-            for (uint32_t j = tid; 2u * j < ntr; j += nthr) {                       // lane: triples 2j, 2j+1 packed in 16-bit halves
-                const uint32_t ya = a.y_off + 26u * j;
-                u16x2 s[13];
+            // One lane = four consecutive triples: 52 symbols (13 aligned dwords of Y) -> 12 pixels = 72 bytes, stored straight
+            // to memory (lanes are consecutive, so a wave writes one contiguous run).  Triples 0/2 and 1/3 share registers as
+            // 16-bit halves; inverse of the encoder's splice (unpack_two_pixels OLD:706-722) in packed arithmetic.
+            const uint32_t ntr = a.TS / 13u;                                       // triples in the tile (a multiple of 4)
+            for (uint32_t j = tid; 4u * j < ntr; j += nthr) {
+                uint32_t D[13];
 #pragma unroll
-                for (int i = 0; i < 13; ++i) s[i] = u16x2{lds[ya + i], lds[ya + 13 + i]};
-                u16x2 q, t, Y0, B0, R0, Y1, B1, R1, Y2, B2, R2;                    // inverse of the encoder's splice (unpack_two_pixels OLD:706-722)
-                q = pd9(s[1]);  Y0 = s[0] + (s[1] - q * (uint16_t)9) * (uint16_t)27;  B0 = q + s[2] * (uint16_t)3;
-                q = pd3(s[4]);  R0 = s[3] + (s[4] - q * (uint16_t)3) * (uint16_t)27;  Y1 = q + s[5] * (uint16_t)9;
-                q = pd3(s[7]);  B1 = s[6] + (s[7] - q * (uint16_t)3) * (uint16_t)27;
-                t = pd9(s[8]);  R1 = q + (s[8] - t * (uint16_t)9) * (uint16_t)9;
-                q = pd3(s[10]); Y2 = t + s[9] * (uint16_t)3 + (s[10] - q * (uint16_t)3) * (uint16_t)81;
-                t = pd9(s[11]); B2 = q + (s[11] - t * (uint16_t)9) * (uint16_t)9;      R2 = t + s[12] * (uint16_t)3;
-                const u16x2 px[9] = {Y0, B0 - (uint16_t)40, R0 - (uint16_t)40, Y1, B1 - (uint16_t)40, R1 - (uint16_t)40, Y2, B2 - (uint16_t)40, R2 - (uint16_t)40};
-                const uint32_t oa = a.o_off + 36u * j;                              // triple 2j at +0, 2j+1 at +18
+                for (int i = 0; i < 13; ++i) D[i] = *(const uint32_t*)(lds + a.y_off + 52u * j + 4u * i);
+                uint32_t o[18];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) { const uint32_t v = bits(px[i]); *(uint16_t*)(lds + oa + 2 * i) = (uint16_t)v; *(uint16_t*)(lds + oa + 18 + 2 * i) = (uint16_t)(v >> 16); }
+                for (uint32_t pair = 0; pair < 2; ++pair) {                         // pair 0 = triples (0, 2), pair 1 = triples (1, 3)
+                    u16x2 sy[13];
+#pragma unroll
+                    for (uint32_t i = 0; i < 13; ++i) {
+                        const uint32_t lo = 13u * pair + i, hi = lo + 26u;          // byte offsets of the two symbols
+                        // v_perm(S0, S1): selector bytes 0..3 pick from S1, 4..7 from S0, 0x0c = zero
+                        const uint32_t sel = (lo & 3u) | 0x0c00u | ((4u + (hi & 3u)) << 16) | 0x0c000000u;
+                        sy[i] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(D[hi >> 2], D[lo >> 2], sel));
+                    }
+                    u16x2 q, t, Y0, B0, R0, Y1, B1, R1, Y2, B2, R2;
+                    q = pd9(sy[1]);  Y0 = sy[0] + (sy[1] - q * (uint16_t)9) * (uint16_t)27;  B0 = q + sy[2] * (uint16_t)3;
+                    q = pd3(sy[4]);  R0 = sy[3] + (sy[4] - q * (uint16_t)3) * (uint16_t)27;  Y1 = q + sy[5] * (uint16_t)9;
+                    q = pd3(sy[7]);  B1 = sy[6] + (sy[7] - q * (uint16_t)3) * (uint16_t)27;
+                    t = pd9(sy[8]);  R1 = q + (sy[8] - t * (uint16_t)9) * (uint16_t)9;
+                    q = pd3(sy[10]); Y2 = t + sy[9] * (uint16_t)3 + (sy[10] - q * (uint16_t)3) * (uint16_t)81;
+                    t = pd9(sy[11]); B2 = q + (sy[11] - t * (uint16_t)9) * (uint16_t)9;      R2 = t + sy[12] * (uint16_t)3;
+                    const uint32_t c[9] = {bits(Y0), bits(B0 - (uint16_t)40), bits(R0 - (uint16_t)40), bits(Y1), bits(B1 - (uint16_t)40), bits(R1 - (uint16_t)40),
+                                           bits(Y2), bits(B2 - (uint16_t)40), bits(R2 - (uint16_t)40)};
+                    // 16-bit output index of component i: first triple of the pair 9 pair + i, second + 18
+                    if (pair == 0) {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) { o[d] = __builtin_amdgcn_perm(c[2 * d + 1], c[2 * d], 0x05040100u); o[9 + d] = __builtin_amdgcn_perm(c[2 * d + 1], c[2 * d], 0x07060302u); }
+                        o[4] = c[8] & 0xFFFFu; o[13] = c[8] >> 16;                  // low halves of dwords 4 and 13; pair 1 supplies the high halves
+                    } else {
+                        o[4] |= c[0] << 16; o[13] |= c[0] & 0xFFFF0000u;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) { o[5 + d] = __builtin_amdgcn_perm(c[2 * d + 2], c[2 * d + 1], 0x05040100u); o[14 + d] = __builtin_amdgcn_perm(c[2 * d + 2], c[2 * d + 1], 0x07060302u); }
+                    }
+                }
+                uint8_t* g = (uint8_t*)a.out + (unit0 + 12ull * j) * 6u;            // 8-byte aligned
+                if (12u * j + 12u <= n_here) {
+                    typedef uint32_t v4u __attribute__((ext_vector_type(4), aligned(8)));
+                    typedef uint32_t v2u __attribute__((ext_vector_type(2), aligned(8)));
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) *(v4u*)(g + 16 * d) = v4u{o[4 * d], o[4 * d + 1], o[4 * d + 2], o[4 * d + 3]};
+                    *(v2u*)(g + 64) = v2u{o[16], o[17]};
+                } else {                                                            // the frame's last pixels: per 16-bit component
+#pragma unroll
+                    for (uint32_t h = 0; h < 36; ++h)
+                        if (12u * j + h / 3u < n_here) *(uint16_t*)(g + 2u * h) = (uint16_t)(o[h >> 1] >> (16u * (h & 1u)));
+                }
             }
         } else {
             const uint32_t ng = a.TS / 26u;                                        // groups of 26 symbols -> 3 words (OLD:1022-1040)
@@ -283,9 +317,9 @@ __global__ __launch_bounds__(512, 4) void decode_fixed_kernel(const DecFxArgs a)
                 for (int i = 0; i < 27; ++i) lds[oa + i] = (uint8_t)o[i];
             }
         }
-        __syncthreads();
-        // coalesced copy-out of the tile's units
-        {
+        if constexpr (!TO_PIXELS) __syncthreads();
+        // coalesced copy-out of the tile's units (raw words; pixels were stored directly)
+        if constexpr (!TO_PIXELS) {
             constexpr uint32_t UB = TO_PIXELS ? 6u : 9u;
             const uint32_t nbytes = n_here * UB;
             uint8_t* g = (uint8_t*)a.out + unit0 * UB;
