@@ -33,7 +33,7 @@ GOLD_HASH_C2 = "b6c43f2f4aa44763"
 
 def cpu_baseline(orc, ol, px, budget_s=30.0):
     """The reference's own encoder (oracle/_ref, built from /root/reference in place) on one full 8K frame, 1 thread;
-    decode leg: the C port of the FIXED decoder on a 1/8-frame sample (the reference cannot decode its own streams)."""
+    decode leg: the C port of the FIXED decoder on a 1/2-frame sample (the reference cannot decode its own streams)."""
     import numpy as np
     cfg = ol.make_cfg(profile=2, uep=2)
     kind = "port"
@@ -47,7 +47,7 @@ def cpu_baseline(orc, ol, px, budget_s=30.0):
         enc_px = len(sample)
     assert rc == 0
     enc_mpix = enc_px / t_enc / 1e6
-    sample = px[: NPX // 8]
+    sample = px[: NPX // 2]
     fcfg = ol.make_cfg(profile=2, uep=2, mode=1)
     rc, fenc = orc.encode_frame(sample, fcfg, cap=len(sample))
     nblk = (len(fenc) * 9 - 90) // 26
@@ -57,7 +57,7 @@ def cpu_baseline(orc, ol, px, budget_s=30.0):
     dec_mpix = len(sample) / t_dec / 1e6
     both = 1.0 / (1.0 / enc_mpix + 1.0 / dec_mpix)
     return {"value": round(both, 4), "unit": "Mpix/s", "cores": 1, "kind": kind,
-            "sample": "encode: %s encoder on %d px of the 8K frame (%.1f s, %.3f Mpix/s); decode: C port of the FIXED decoder on the first 1/8 frame with injected errors (%.1f s, %.3f Mpix/s); value = 1/(1/enc+1/dec)"
+            "sample": "encode: %s encoder on %d px of the 8K frame (%.1f s, %.3f Mpix/s); decode: C port of the FIXED decoder on the first 1/2 frame with injected errors (%.1f s, %.3f Mpix/s); value = 1/(1/enc+1/dec)"
                       % ("unmodified reference" if kind == "reference" else "C port of the reference", enc_px, t_enc, enc_mpix, t_dec, dec_mpix),
             "encode_mpix_s": round(enc_mpix, 4), "decode_mpix_s": round(dec_mpix, 4)}
 

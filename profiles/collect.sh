@@ -2,7 +2,8 @@
 # Evidence run on the GPU box (one gpurun call):  bash profiles/collect.sh <tag>
 #   1. GPU parity tests                               -> gpurun_out/<tag>_pytest.log
 #   2. bench.py, default flags (incl. cpu_baseline)   -> gpurun_out/<tag>_bench.json
-#   3. rocprofv3 --kernel-trace --stats of bench.py   -> gpurun_out/<tag>_kernel_stats.csv   (no counters in this pass)
+#   3. rocprofv3 --kernel-trace --stats of bench.py   -> gpurun_out/<tag>_kernel_stats.csv (record overlapped with decode, as benched)
+#      and of bench.py --serial                       -> gpurun_out/<tag>_kernel_stats_serial.csv (every kernel alone); no counters in these passes
 #   4. PMC passes on the encode kernel (own passes)   -> gpurun_out/pmc_<tag>_summary.json + gpurun_out/<tag>_pmc_encode_latest.json
 # Copy what is to be kept into profiles/ afterwards.
 cd "$(dirname "$0")/.."; export TMPDIR=/tmp
@@ -11,6 +12,9 @@ timeout -k 10 600 python3 -m pytest tests -m gpu -q > gpurun_out/${tag}_pytest.l
 python3 bench.py 2> gpurun_out/${tag}_bench.err | tail -1 > gpurun_out/${tag}_bench.json; cut -c1-400 gpurun_out/${tag}_bench.json
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_kt -o kt --output-format csv -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/${tag}_kt.log 2>&1
 cp gpurun_out/${tag}_kt/kt_kernel_stats.csv gpurun_out/${tag}_kernel_stats.csv 2>/dev/null; head -7 gpurun_out/${tag}_kernel_stats.csv | cut -c1-160
+# the same with the index record on the main stream: every kernel runs alone (its stand-alone duration)
+rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_kts -o kt --output-format csv -- python3 bench.py --serial --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/${tag}_kts.log 2>&1
+cp gpurun_out/${tag}_kts/kt_kernel_stats.csv gpurun_out/${tag}_kernel_stats_serial.csv 2>/dev/null; head -6 gpurun_out/${tag}_kernel_stats_serial.csv | cut -c1-160
 bash profiles/pmc_encode.sh ${tag} > gpurun_out/${tag}_pmc.txt 2>&1
 python3 - <<PY
 import json
