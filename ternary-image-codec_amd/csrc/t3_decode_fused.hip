@@ -175,10 +175,14 @@ __global__ __launch_bounds__(512, 4) void decode_fixed_kernel(const DecFxArgs a)
 #pragma unroll
                 for (int q = 0; q < 6; ++q) dbase[q] = DSC + 32u * ((a.cyc24 >> (2u * (c0 + q))) & 3u);
                 const bool first = rw.body_off == 0 && mg == 0;
-                uint32_t c[26]; bool big = false;
+                uint32_t c[26];
 #pragma unroll
-                for (int i = 0; i < 26; ++i) { c[i] = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu; big |= c[i] >= 27u; }
-                if (__builtin_amdgcn_ballot_w64(big) != 0) {
+                for (int i = 0; i < 26; ++i) c[i] = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                // any byte >= 27?  (b + 101) sets bit 7 exactly for b in 27..154, and a byte >= 155 has bit 7 set already
+                uint32_t hi = 0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) hi |= (w[i] | (w[i] + 0x65656565u));   // a carry out of a byte only ever adds set bits
+                if (__builtin_amdgcn_ballot_w64((hi & 0x80808080u) != 0u) != 0) {
 #pragma unroll
                     for (int i = 0; i < 26; ++i) c[i] -= 27u * d27(c[i]);           // unpack3 semantics for non-canonical bytes
                 }
