@@ -196,6 +196,28 @@ uint64_t t3hip_frame_record_scratch_bytes(uint64_t n_words);
 /* Host: sort gathered records by frame_idx and fill byte_offset (T3V index, io_t3p_t3v.cpp:252-289). */
 int t3hip_index_assemble(t3_frame_record* recs, uint64_t n_recs, uint64_t first_payload_offset);
 
+/* ---- subword trit streams and wire packings ------------------------------
+ * One byte per trit (0..2) on the trit side.  N = trits kept per word (SubwordMode: 27/24/21/18/15; any 1..27 accepted).
+ *   extract : extract_subword_stream_from_words  OLD:834-844 -> n_words * N trits (first N trits of every word)
+ *   build   : build_words_from_subword_stream    OLD:845-859 -> ceil(n_trits / N) words; slots N..26 = fill, a short last
+ *             group is zero-padded up to N
+ *   base243 : tpack::ut_to_base243 / base243_to_ut  TPACK:28-50: uint32 LE trit count, then 5 trits per byte (LSD first);
+ *             unpack returns T3_E_HEADER where the reference returns false (short input, fewer trits than announced)
+ *   mod27   : tpack::words_to_bytes / bytes_to_words  TPACK:53-65: every byte % 27 (callers check n % 9 for bytes_to_words) */
+uint64_t t3hip_subword_words(uint64_t n_trits, int N);
+uint64_t t3hip_base243_bytes(uint64_t n_trits);
+int t3hip_subword_extract(const void* words9, uint64_t n_words, int N, uint8_t* trits);
+int t3hip_subword_build(const uint8_t* trits, uint64_t n_trits, int N, uint8_t fill, void* words9, uint64_t cap_words, uint64_t* n_words);
+int t3hip_base243_pack(const uint8_t* trits, uint64_t n_trits, uint8_t* out, uint64_t cap_bytes, uint64_t* n_bytes);
+int t3hip_base243_unpack(const uint8_t* in, uint64_t n_bytes, uint8_t* trits, uint64_t cap_trits, uint64_t* n_trits);
+int t3hip_mod27_bytes(const uint8_t* in, uint64_t n, uint8_t* out);
+int t3hip_subword_extract_dev(const void* d_words9, uint64_t n_words, int N, uint8_t* d_trits, void* stream);
+int t3hip_subword_build_dev(const uint8_t* d_trits, uint64_t n_trits, int N, uint8_t fill, void* d_words9, uint64_t cap_words, uint64_t* n_words, void* stream);
+int t3hip_base243_pack_dev(const uint8_t* d_trits, uint64_t n_trits, uint8_t* d_out, uint64_t cap_bytes, uint64_t* n_bytes, void* stream);
+/* total = the trit count of the 4-byte header (the host entry point reads it itself) */
+int t3hip_base243_unpack_dev(const uint8_t* d_in, uint64_t n_bytes, uint64_t total, uint8_t* d_trits, void* stream);
+int t3hip_mod27_bytes_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, void* stream);
+
 /* ---- timing helper: HIP events on the caller's stream -------------------------------- */
 int t3hip_event_create(void** ev);
 int t3hip_event_record(void* ev, void* stream);

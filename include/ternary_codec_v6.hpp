@@ -174,6 +174,53 @@ inline bool decode_raw_words_to_pixels_subword(const std::vector<Word27>& in, Su
     return decode_raw_words_to_pixels(in, out);
 }
 
+// ---- subword trit streams (OLD:834-859) and wire packings (include/ternary_packing.hpp, namespace tpack) --------------
+inline void extract_subword_stream_from_words(const std::vector<Word27>& words, int N, std::vector<UTrit>& out) {
+    out.clear();
+    if (N < 1 || N > 27 || !t3::ensure_device()) return;
+    out.resize(words.size() * (size_t)N);
+    if (!t3::ok(t3hip_subword_extract(words.data(), words.size(), N, out.data()))) out.clear();
+}
+inline void build_words_from_subword_stream(const std::vector<UTrit>& in, int N, std::vector<Word27>& out, UTrit fill = 0) {
+    out.clear();
+    if (N < 1 || N > 27 || !t3::ensure_device()) return;
+    out.resize((size_t)t3hip_subword_words(in.size(), N));
+    uint64_t nw = 0;
+    if (!t3::ok(t3hip_subword_build(in.data(), in.size(), N, fill, out.data(), out.size(), &nw))) { out.clear(); return; }
+    out.resize((size_t)nw);
+}
+namespace tpack {
+inline void ut_to_base243(const std::vector<UTrit>& in, std::vector<uint8_t>& out) {   // TPACK:28-38
+    out.clear();
+    if (!t3::ensure_device()) return;
+    out.resize((size_t)t3hip_base243_bytes(in.size()));
+    uint64_t nb = 0;
+    if (!t3::ok(t3hip_base243_pack(in.data(), in.size(), out.data(), out.size(), &nb))) { out.clear(); return; }
+    out.resize((size_t)nb);
+}
+inline bool base243_to_ut(const std::vector<uint8_t>& in, std::vector<UTrit>& out) {     // TPACK:40-50
+    out.clear();
+    if (in.size() < 4 || !t3::ensure_device()) return false;
+    out.resize(5 * (in.size() - 4));
+    uint64_t nt = 0;
+    if (!t3::ok(t3hip_base243_unpack(in.data(), in.size(), out.data(), out.size(), &nt))) { out.clear(); return false; }
+    out.resize((size_t)nt);
+    return true;
+}
+inline void words_to_bytes(const std::vector<Word27>& words, std::vector<uint8_t>& out) {  // TPACK:53-58
+    out.clear();
+    if (!t3::ensure_device()) return;
+    out.resize(words.size() * 9);
+    if (!t3::ok(t3hip_mod27_bytes((const uint8_t*)words.data(), out.size(), out.data()))) out.clear();
+}
+inline void bytes_to_words(const std::vector<uint8_t>& in, std::vector<Word27>& out) {     // TPACK:60-65
+    out.clear();
+    if (in.size() % 9 != 0 || !t3::ensure_device()) return;
+    out.resize(in.size() / 9);
+    if (!t3::ok(t3hip_mod27_bytes(in.data(), in.size(), (uint8_t*)out.data()))) out.clear();
+}
+}  // namespace tpack
+
 // ---- profile encode / decode (OLD:995-1169) --------------------------------------------------------------------------
 inline bool encode_profile_from_raw(const std::vector<Word27>& in, std::vector<Word27>& out, EncoderContext& ectx) {
     out.clear();

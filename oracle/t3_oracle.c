@@ -644,6 +644,38 @@ void t3o_lcg_pixels(void* px6, uint64_t n_px, uint32_t seed) { /* SURVEY §8d / 
         s = s * 1664525u + 1013904223u; px[i].Cr = (int16_t)((int)((s >> 8) % 81) - 40);
     }
 }
+/* ---- row f1: RGB8 <-> quantised YCbCr (old/include/io_image.hpp:47-90).  float products and sums are rounded one by
+ * one, left to right, as the reference's expressions evaluate on x86-64 SSE (no fused multiply-add: the Makefile passes
+ * -ffp-contract=off); lround = round half away from zero; quantisation in double. ---- */
+#include <math.h>
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+void t3o_rgb_to_quant(const uint8_t* rgb, uint64_t n_px, void* px6) {
+    uint8_t* o = (uint8_t*)px6;
+    for (uint64_t i = 0; i < n_px; ++i) {
+        const float r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+        const float y = 0.299f * r + 0.587f * g + 0.114f * b;                       /* io_image.hpp:50 */
+        const float cb = -0.168736f * r - 0.331264f * g + 0.5f * b + 128.0f;        /* :51 */
+        const float cr = 0.5f * r - 0.418688f * g - 0.081312f * b + 128.0f;         /* :52 */
+        const int Y = clampi((int)lroundf(y), 0, 255), Cb = clampi((int)lroundf(cb), 0, 255), Cr = clampi((int)lroundf(cr), 0, 255);
+        const uint16_t Yq = (uint16_t)clampi((int)lround(Y * (242.0 / 255.0)), 0, 242);   /* :72 */
+        const int16_t Cbq = (int16_t)clampi((int)lround((Cb - 128) * (40.0 / 128.0)), -40, 40);
+        const int16_t Crq = (int16_t)clampi((int)lround((Cr - 128) * (40.0 / 128.0)), -40, 40);
+        memcpy(o + 6 * i, &Yq, 2); memcpy(o + 6 * i + 2, &Cbq, 2); memcpy(o + 6 * i + 4, &Crq, 2);
+    }
+}
+void t3o_quant_to_rgb(const void* px6, uint64_t n_px, uint8_t* rgb) {
+    const uint8_t* p = (const uint8_t*)px6;
+    for (uint64_t i = 0; i < n_px; ++i) {
+        uint16_t Yq; int16_t Cbq, Crq; memcpy(&Yq, p + 6 * i, 2); memcpy(&Cbq, p + 6 * i + 2, 2); memcpy(&Crq, p + 6 * i + 4, 2);
+        const uint8_t Y = (uint8_t)clampi((int)lround(Yq * (255.0 / 242.0)), 0, 255);      /* io_image.hpp:81 */
+        const uint8_t Cb = (uint8_t)clampi((int)lround(128 + Cbq * (128.0 / 40.0)), 0, 255);
+        const uint8_t Cr = (uint8_t)clampi((int)lround(128 + Crq * (128.0 / 40.0)), 0, 255);
+        const float y = Y, cb = Cb - 128.0f, cr = Cr - 128.0f;                            /* :59 */
+        const float r = y + 1.402f * cr, g = y - 0.344136f * cb - 0.714136f * cr, b = y + 1.772f * cb;
+        rgb[3 * i] = (uint8_t)clampi((int)lroundf(r), 0, 255); rgb[3 * i + 1] = (uint8_t)clampi((int)lroundf(g), 0, 255); rgb[3 * i + 2] = (uint8_t)clampi((int)lroundf(b), 0, 255);
+    }
+}
+
 void t3o_lcg_rgb(uint8_t* rgb, uint64_t n_px, uint32_t seed) { uint32_t s = seed; for (uint64_t i = 0; i < 3 * n_px; ++i) { s = s * 1664525u + 1013904223u; rgb[i] = (uint8_t)((s >> 8) % 256); } }
 
 /* counter hash shared with the device injector (csrc/t3_kernels.hip: inject_errors_kernel) */

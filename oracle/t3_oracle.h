@@ -55,6 +55,10 @@ int64_t  t3o_base243_to_ut(const uint8_t* bytes, uint64_t n, uint8_t* trits_out)
 void     t3o_words_to_bytes(const void* words9, uint64_t n_words, uint8_t* out);
 uint64_t t3o_bytes_to_words(const uint8_t* bytes, uint64_t n, void* words9);
 
+/* row f1: RGB8 <-> quantised YCbCr bridge, old/include/io_image.hpp:47-90,156-195 */
+void     t3o_rgb_to_quant(const uint8_t* rgb, uint64_t n_px, void* px6);    /* rgb_to_quant_stream */
+void     t3o_quant_to_rgb(const void* px6, uint64_t n_px, uint8_t* rgb);    /* quant_stream_to_rgb */
+
 /* checkers' utilities */
 uint64_t t3o_fnv1a64(const void* data, uint64_t n);
 uint32_t t3o_crc32(const void* data, uint64_t n);

@@ -267,6 +267,83 @@ def decode_raw_words_to_pixels_subword(words, sub):  # NEWH:123-125 / NEWC:148-1
     return decode_raw_words_to_pixels(words)
 
 
+# ---- subword trit streams and wire packings (OLD:834-859, TPACK:18-65) ----------------------------
+def _u8(a):
+    return np.ascontiguousarray(a, np.uint8).reshape(-1)
+
+
+def extract_subword_stream_from_words(words, N):  # OLD:834-844 -> uint8 trits, N per word
+    w = np.ascontiguousarray(words, np.uint8).reshape(-1, 9); n = len(w)
+    out = np.zeros(n * int(N), np.uint8)
+    _chk(lib().t3hip_subword_extract(_vp(w), C.c_uint64(n), C.c_int(int(N)), _vp(out)), "t3hip_subword_extract")
+    return out
+
+
+def build_words_from_subword_stream(trits, N, fill=0):  # OLD:845-859 -> Word27 array
+    t = _u8(trits)
+    lib().t3hip_subword_words.restype = C.c_uint64
+    cap = int(lib().t3hip_subword_words(C.c_uint64(len(t)), C.c_int(int(N))))
+    out = np.zeros((cap, 9), np.uint8); nw = C.c_uint64()
+    _chk(lib().t3hip_subword_build(_vp(t), C.c_uint64(len(t)), C.c_int(int(N)), C.c_uint8(fill), _vp(out), C.c_uint64(cap), C.byref(nw)), "t3hip_subword_build")
+    return out[: nw.value]
+
+
+def ut_to_base243(trits):  # TPACK:28-38
+    t = _u8(trits)
+    lib().t3hip_base243_bytes.restype = C.c_uint64
+    cap = int(lib().t3hip_base243_bytes(C.c_uint64(len(t))))
+    out = np.zeros(cap, np.uint8); nb = C.c_uint64()
+    _chk(lib().t3hip_base243_pack(_vp(t), C.c_uint64(len(t)), _vp(out), C.c_uint64(cap), C.byref(nb)), "t3hip_base243_pack")
+    return out[: nb.value]
+
+
+def base243_to_ut(data):  # TPACK:40-50 -> trits, or None where the reference returns false
+    b = _u8(data)
+    cap = 5 * max(len(b), 4)
+    out = np.zeros(cap, np.uint8); nt = C.c_uint64()
+    rc = lib().t3hip_base243_unpack(_vp(b), C.c_uint64(len(b)), _vp(out), C.c_uint64(cap), C.byref(nt))
+    if rc == E_HEADER:
+        return None
+    _chk(rc, "t3hip_base243_unpack")
+    return out[: nt.value]
+
+
+def words_to_bytes(words):  # TPACK:53-58
+    w = np.ascontiguousarray(words, np.uint8).reshape(-1)
+    out = np.zeros(len(w), np.uint8)
+    _chk(lib().t3hip_mod27_bytes(_vp(w), C.c_uint64(len(w)), _vp(out)), "t3hip_mod27_bytes")
+    return out
+
+
+def bytes_to_words(data):  # TPACK:60-65: nothing unless len % 9 == 0
+    b = _u8(data)
+    if len(b) % 9:
+        return np.zeros((0, 9), np.uint8)
+    out = np.zeros(len(b), np.uint8)
+    _chk(lib().t3hip_mod27_bytes(_vp(b), C.c_uint64(len(b)), _vp(out)), "t3hip_mod27_bytes")
+    return out.reshape(-1, 9)
+
+
+def subword_extract_dev(d_words, n_words, N, d_trits, stream=0):
+    _chk(lib().t3hip_subword_extract_dev(C.c_void_p(d_words), C.c_uint64(n_words), C.c_int(int(N)), C.c_void_p(d_trits), C.c_void_p(stream)), "t3hip_subword_extract_dev")
+
+
+def subword_build_dev(d_trits, n_trits, N, fill, d_words, cap_words, stream=0):
+    nw = C.c_uint64()
+    _chk(lib().t3hip_subword_build_dev(C.c_void_p(d_trits), C.c_uint64(n_trits), C.c_int(int(N)), C.c_uint8(fill), C.c_void_p(d_words), C.c_uint64(cap_words), C.byref(nw), C.c_void_p(stream)), "t3hip_subword_build_dev")
+    return nw.value
+
+
+def base243_pack_dev(d_trits, n_trits, d_out, cap_bytes, stream=0):
+    nb = C.c_uint64()
+    _chk(lib().t3hip_base243_pack_dev(C.c_void_p(d_trits), C.c_uint64(n_trits), C.c_void_p(d_out), C.c_uint64(cap_bytes), C.byref(nb), C.c_void_p(stream)), "t3hip_base243_pack_dev")
+    return nb.value
+
+
+def base243_unpack_dev(d_in, n_bytes, total, d_trits, stream=0):
+    _chk(lib().t3hip_base243_unpack_dev(C.c_void_p(d_in), C.c_uint64(n_bytes), C.c_uint64(total), C.c_void_p(d_trits), C.c_void_p(stream)), "t3hip_base243_unpack_dev")
+
+
 def encode_profile_from_raw(raw_words, ectx):  # OLD:1043-1169 -> (True, words)
     cfg = ectx.cfg if isinstance(ectx, EncoderContext) else ectx
     raw = np.ascontiguousarray(raw_words, np.uint8).reshape(-1, 9)

@@ -1,0 +1,152 @@
+// t3_api_subword.cpp — C-ABI of SURVEY §8 row f3: subword trit streams (OLD:834-859) and the wire packings of
+// include/ternary_packing.hpp (TPACK:18-65).  Device entry points launch on the caller's stream; host entry points stage
+// through the library's scratch buffers like the rest of the std::vector-facing API.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "../../include/t3hip.h"
+#include "t3_subword.h"
+
+namespace t3 {
+int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out);
+int api_fail_hip(hipError_t e, const char* what);
+}  // namespace t3
+using namespace t3;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return api_fail_hip(e_, #x); } while (0)
+
+namespace {
+unsigned blocks_for(uint64_t items) { return (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, (items + 255) / 256), 1u << 30); }
+bool valid_n(int N) { return N >= 1 && N <= 27; }
+}  // namespace
+
+extern "C" {
+
+uint64_t t3hip_subword_words(uint64_t n_trits, int N) { return N >= 1 ? (n_trits + (uint64_t)N - 1) / (uint64_t)N : 0; }
+uint64_t t3hip_base243_bytes(uint64_t n_trits) { return 4 + (n_trits + 4) / 5; }
+
+int t3hip_subword_extract_dev(const void* d_words, uint64_t n_words, int N, uint8_t* d_trits, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!valid_n(N)) return T3_E_ARG;
+    if (!n_words) return T3_OK;
+    if (!d_words || !d_trits) return T3_E_ARG;
+    // < 2^32 trits per launch; chunks of a multiple of 4 words keep every chunk's output dword-aligned
+    const uint64_t chunk = (0xF0000000ull / (uint64_t)N) & ~3ull;
+    for (uint64_t w0 = 0; w0 < n_words; w0 += chunk) {
+        const uint64_t nw = std::min(chunk, n_words - w0);
+        hipLaunchKernelGGL(subword_extract_kernel, dim3(blocks_for((nw * (uint64_t)N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint8_t*)d_words + 9 * w0, nw, N, d_trits + w0 * (uint64_t)N);
+        HIPCHK(hipGetLastError());
+    }
+    return T3_OK;
+}
+
+int t3hip_subword_build_dev(const uint8_t* d_trits, uint64_t n_trits, int N, uint8_t fill, void* d_words, uint64_t cap_words, uint64_t* n_words, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!valid_n(N) || !n_words) return T3_E_ARG;
+    *n_words = t3hip_subword_words(n_trits, N);                           // OLD:845-859: one word per started group of N trits
+    if (*n_words > cap_words) return T3_E_CAPACITY;
+    if (!*n_words) return T3_OK;
+    if (!d_trits || !d_words) return T3_E_ARG;
+    hipLaunchKernelGGL(subword_build_kernel, dim3(blocks_for(*n_words)), dim3(256), 0, (hipStream_t)stream, d_trits, n_trits, N, (uint32_t)fill, (uint8_t*)d_words, *n_words);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+
+int t3hip_base243_pack_dev(const uint8_t* d_trits, uint64_t n_trits, uint8_t* d_out, uint64_t cap_bytes, uint64_t* n_bytes, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!n_bytes || n_trits > 0xFFFFFFFFull) return T3_E_ARG;             // the header holds a uint32 count (TPACK:31)
+    *n_bytes = t3hip_base243_bytes(n_trits);
+    if (*n_bytes > cap_bytes) return T3_E_CAPACITY;
+    if (!d_out || (n_trits && !d_trits)) return T3_E_ARG;
+    hipLaunchKernelGGL(base243_pack_kernel, dim3(blocks_for((n_trits + 4) / 5)), dim3(256), 0, (hipStream_t)stream, d_trits, n_trits, d_out);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+
+// `total` = the count read from the 4-byte header (t3hip_base243_unpack reads it; device pipelines know it)
+int t3hip_base243_unpack_dev(const uint8_t* d_in, uint64_t n_bytes, uint64_t total, uint8_t* d_trits, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (n_bytes < 4) return T3_E_HEADER;                                   // TPACK:41
+    if (total > 5 * (n_bytes - 4)) return T3_E_HEADER;                     // TPACK:49: fewer trits than announced -> false
+    if (!total) return T3_OK;
+    if (!d_in || !d_trits) return T3_E_ARG;
+    hipLaunchKernelGGL(base243_unpack_kernel, dim3(blocks_for(n_bytes - 4)), dim3(256), 0, (hipStream_t)stream, d_in + 4, n_bytes - 4, total, d_trits);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+
+int t3hip_mod27_bytes_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!n) return T3_OK;
+    if (!d_in || !d_out) return T3_E_ARG;
+    hipLaunchKernelGGL(mod27_bytes_kernel, dim3(blocks_for((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_in, n, d_out);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+
+// ---- host-buffer entry points (what the std::vector API of include/ternary_codec_v6.hpp binds) ----
+static int roundtrip(const void* in, uint64_t in_bytes, void** di, uint64_t out_bytes, void** dout) {
+    int rc = api_scratch(0, in_bytes + 64, di); if (rc) return rc;
+    rc = api_scratch(1, out_bytes + 64, dout); if (rc) return rc;
+    if (in_bytes) HIPCHK(hipMemcpyAsync(*di, in, in_bytes, hipMemcpyHostToDevice, api_stream()));
+    return T3_OK;
+}
+static int fetch(void* out, const void* dout, uint64_t bytes) {
+    if (bytes) HIPCHK(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, api_stream()));
+    HIPCHK(hipStreamSynchronize(api_stream())); return T3_OK;
+}
+
+int t3hip_subword_extract(const void* words9, uint64_t n_words, int N, uint8_t* trits) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!valid_n(N)) return T3_E_ARG;
+    if (!n_words) return T3_OK;
+    if (!words9 || !trits) return T3_E_ARG;
+    void *di, *dout; int rc = roundtrip(words9, n_words * 9, &di, n_words * (uint64_t)N, &dout); if (rc) return rc;
+    rc = t3hip_subword_extract_dev(di, n_words, N, (uint8_t*)dout, api_stream()); if (rc) return rc;
+    return fetch(trits, dout, n_words * (uint64_t)N);
+}
+int t3hip_subword_build(const uint8_t* trits, uint64_t n_trits, int N, uint8_t fill, void* words9, uint64_t cap_words, uint64_t* n_words) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!valid_n(N) || !n_words || (n_trits && !trits)) return T3_E_ARG;
+    const uint64_t nw = t3hip_subword_words(n_trits, N); *n_words = nw;
+    if (nw > cap_words) return T3_E_CAPACITY;
+    if (!nw) return T3_OK;
+    if (!words9) return T3_E_ARG;
+    void *di, *dout; int rc = roundtrip(trits, n_trits, &di, nw * 9, &dout); if (rc) return rc;
+    rc = t3hip_subword_build_dev((const uint8_t*)di, n_trits, N, fill, dout, nw, n_words, api_stream()); if (rc) return rc;
+    return fetch(words9, dout, nw * 9);
+}
+int t3hip_base243_pack(const uint8_t* trits, uint64_t n_trits, uint8_t* out, uint64_t cap_bytes, uint64_t* n_bytes) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!n_bytes || n_trits > 0xFFFFFFFFull || (n_trits && !trits)) return T3_E_ARG;
+    *n_bytes = t3hip_base243_bytes(n_trits);
+    if (*n_bytes > cap_bytes) return T3_E_CAPACITY;
+    if (!out) return T3_E_ARG;
+    void *di, *dout; int rc = roundtrip(trits, n_trits, &di, *n_bytes, &dout); if (rc) return rc;
+    rc = t3hip_base243_pack_dev((const uint8_t*)di, n_trits, (uint8_t*)dout, *n_bytes, n_bytes, api_stream()); if (rc) return rc;
+    return fetch(out, dout, *n_bytes);
+}
+int t3hip_base243_unpack(const uint8_t* in, uint64_t n_bytes, uint8_t* trits, uint64_t cap_trits, uint64_t* n_trits) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!n_trits || (n_bytes && !in)) return T3_E_ARG;
+    *n_trits = 0;
+    if (n_bytes < 4) return T3_E_HEADER;
+    uint32_t total; memcpy(&total, in, 4);
+    if ((uint64_t)total > 5 * (n_bytes - 4)) return T3_E_HEADER;
+    *n_trits = total;
+    if (total > cap_trits) return T3_E_CAPACITY;
+    if (!total) return T3_OK;
+    if (!trits) return T3_E_ARG;
+    void *di, *dout; int rc = roundtrip(in, n_bytes, &di, total, &dout); if (rc) return rc;
+    rc = t3hip_base243_unpack_dev((const uint8_t*)di, n_bytes, total, (uint8_t*)dout, api_stream()); if (rc) return rc;
+    return fetch(trits, dout, total);
+}
+int t3hip_mod27_bytes(const uint8_t* in, uint64_t n, uint8_t* out) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!n) return T3_OK;
+    if (!in || !out) return T3_E_ARG;
+    void *di, *dout; int rc = roundtrip(in, n, &di, n, &dout); if (rc) return rc;
+    rc = t3hip_mod27_bytes_dev((const uint8_t*)di, n, (uint8_t*)dout, api_stream()); if (rc) return rc;
+    return fetch(out, dout, n);
+}
+
+}  // extern "C"

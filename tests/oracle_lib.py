@@ -268,6 +268,19 @@ class Oracle(_Lib):
         self._f("lcg_pixels", None)(_vp(px), C.c_uint64(n_px), C.c_uint32(seed))
         return px
 
+    # ---- row f1: RGB8 <-> quantised YCbCr bridge (old/include/io_image.hpp:156-195) ------------------------
+    def rgb_to_quant(self, rgb):
+        rgb = np.ascontiguousarray(rgb, np.uint8).reshape(-1)
+        px = np.zeros(len(rgb) // 3, PIXEL_DT)
+        self._f("rgb_to_quant", None)(_u8p(rgb), C.c_uint64(len(px)), _vp(px))
+        return px
+
+    def quant_to_rgb(self, px):
+        px = np.ascontiguousarray(px)
+        rgb = np.zeros(3 * len(px), np.uint8)
+        self._f("quant_to_rgb", None)(_vp(px), C.c_uint64(len(px)), _u8p(rgb))
+        return rgb
+
     def lcg_rgb(self, n_px, seed=12345):
         rgb = np.zeros(3 * n_px, np.uint8)
         self._f("lcg_rgb", None)(_u8p(rgb), C.c_uint64(n_px), C.c_uint32(seed))
