@@ -218,6 +218,16 @@ int t3hip_base243_pack_dev(const uint8_t* d_trits, uint64_t n_trits, uint8_t* d_
 int t3hip_base243_unpack_dev(const uint8_t* d_in, uint64_t n_bytes, uint64_t total, uint8_t* d_trits, void* stream);
 int t3hip_mod27_bytes_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, void* stream);
 
+/* ---- SURVEY 8 row f1 (first version, own kernels): RGB8 <-> quantised YCbCr bridge ------------
+ * rgb_to_quant_stream / quant_stream_to_rgb, old/include/io_image.hpp:47-90,156-195: float BT.601-style conversion with
+ * std::lround and clamps, then quantisation in double.  rgb = 3 bytes per pixel (R,G,B), px6 = PixelYCbCrQuant[n_px].
+ * Bit-exact against the oracle's restatement for all 2^24 RGB values; parity UNPINNED against a reference build (that
+ * header does not compile: ImageU8::swap, old/include/io_image.hpp:218). */
+int t3hip_rgb_to_quant(const uint8_t* rgb, uint64_t n_px, void* px6);
+int t3hip_quant_to_rgb(const void* px6, uint64_t n_px, uint8_t* rgb);
+int t3hip_rgb_to_quant_dev(const uint8_t* d_rgb, uint64_t n_px, void* d_px6, void* stream);
+int t3hip_quant_to_rgb_dev(const void* d_px6, uint64_t n_px, uint8_t* d_rgb, void* stream);
+
 /* ---- timing helper: HIP events on the caller's stream -------------------------------- */
 int t3hip_event_create(void** ev);
 int t3hip_event_record(void* ev, void* stream);

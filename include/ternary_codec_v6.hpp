@@ -174,6 +174,24 @@ inline bool decode_raw_words_to_pixels_subword(const std::vector<Word27>& in, Su
     return decode_raw_words_to_pixels(in, out);
 }
 
+// ---- RGB8 <-> quantised YCbCr bridge (old/include/io_image.hpp:17-21,156-195) --------------------------------------------
+struct ImageU8 { int w = 0, h = 0, c = 0; std::vector<uint8_t> data; };
+inline void rgb_to_quant_stream(const ImageU8& rgb, std::vector<PixelYCbCrQuant>& out) {
+    out.clear();
+    const size_t n = (size_t)(rgb.w > 0 ? rgb.w : 0) * (size_t)(rgb.h > 0 ? rgb.h : 0);
+    if (!n || rgb.data.size() < 3 * n || !t3::ensure_device()) return;
+    out.resize(n);
+    if (!t3::ok(t3hip_rgb_to_quant(rgb.data.data(), n, out.data()))) out.clear();
+}
+inline void quant_stream_to_rgb(const std::vector<PixelYCbCrQuant>& q, int w, int h, ImageU8& out) {
+    out.w = w; out.h = h; out.c = 3;
+    const size_t n = (size_t)(w > 0 ? w : 0) * (size_t)(h > 0 ? h : 0);
+    out.data.assign(n * 3, 0);
+    const size_t m = q.size() < n ? q.size() : n;                     // io_image.hpp:181: stops when the stream runs out
+    if (!m || !t3::ensure_device()) return;
+    t3::ok(t3hip_quant_to_rgb(q.data(), m, out.data.data()));
+}
+
 // ---- subword trit streams (OLD:834-859) and wire packings (include/ternary_packing.hpp, namespace tpack) --------------
 inline void extract_subword_stream_from_words(const std::vector<Word27>& words, int N, std::vector<UTrit>& out) {
     out.clear();

@@ -4,6 +4,10 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the product
  * (ternary-image-codec_amd/) never does.  Pinned against the unmodified reference through
  * oracle/_ref (tests/test_oracle_vs_ref.py) and the committed vectors in tests/golden/.
+ * Exceptions: the FIXED-mode ("v6c") functions restate this repo's own spec (the reference has no such behaviour), and
+ * t3o_rgb_to_quant / t3o_quant_to_rgb (row f1) are PARITY UNPINNED: old/include/io_image.hpp does not compile in this
+ * image (ImageU8 has no member `swap`, :218), so they are checked only against an independent numpy restatement of the
+ * same expressions on all 2^24 inputs (tests/test_oracle_rgb.py).
  */
 #ifndef T3_ORACLE_H
 #define T3_ORACLE_H

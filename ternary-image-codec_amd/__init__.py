@@ -324,6 +324,29 @@ def bytes_to_words(data):  # TPACK:60-65: nothing unless len % 9 == 0
     return out.reshape(-1, 9)
 
 
+# ---- RGB8 <-> quantised YCbCr bridge (old/include/io_image.hpp:156-195) ---------------------------------
+def rgb_to_quant_stream(rgb):  # (n, 3) or flat uint8 RGB -> PixelYCbCrQuant array
+    r = _u8(rgb); n = len(r) // 3
+    px = np.zeros(n, PIXEL_DT)
+    _chk(lib().t3hip_rgb_to_quant(_vp(r), C.c_uint64(n), _vp(px)), "t3hip_rgb_to_quant")
+    return px
+
+
+def quant_stream_to_rgb(px):  # PixelYCbCrQuant array -> flat uint8 RGB
+    p = np.ascontiguousarray(px, PIXEL_DT)
+    out = np.zeros(3 * len(p), np.uint8)
+    _chk(lib().t3hip_quant_to_rgb(_vp(p), C.c_uint64(len(p)), _vp(out)), "t3hip_quant_to_rgb")
+    return out
+
+
+def rgb_to_quant_dev(d_rgb, n_px, d_px, stream=0):
+    _chk(lib().t3hip_rgb_to_quant_dev(C.c_void_p(d_rgb), C.c_uint64(n_px), C.c_void_p(d_px), C.c_void_p(stream)), "t3hip_rgb_to_quant_dev")
+
+
+def quant_to_rgb_dev(d_px, n_px, d_rgb, stream=0):
+    _chk(lib().t3hip_quant_to_rgb_dev(C.c_void_p(d_px), C.c_uint64(n_px), C.c_void_p(d_rgb), C.c_void_p(stream)), "t3hip_quant_to_rgb_dev")
+
+
 def subword_extract_dev(d_words, n_words, N, d_trits, stream=0):
     _chk(lib().t3hip_subword_extract_dev(C.c_void_p(d_words), C.c_uint64(n_words), C.c_int(int(N)), C.c_void_p(d_trits), C.c_void_p(stream)), "t3hip_subword_extract_dev")
 

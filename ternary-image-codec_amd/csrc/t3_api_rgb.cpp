@@ -1,0 +1,77 @@
+// t3_api_rgb.cpp — C-ABI of SURVEY §8 row f1 (RGB8 <-> quantised YCbCr bridge, old/include/io_image.hpp:47-90,156-195)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "../../include/t3hip.h"
+#include "t3_rgb.h"
+
+namespace t3 {
+int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out);
+int api_fail_hip(hipError_t e, const char* what);
+}  // namespace t3
+using namespace t3;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return api_fail_hip(e_, #x); } while (0)
+
+namespace {
+QuantTables* d_qt = nullptr;
+int tables(const QuantTables** out) {
+    if (!d_qt) {
+        QuantTables t; memset(&t, 0, sizeof t);
+        auto cl = [](long v, long lo, long hi) { return v < lo ? lo : (v > hi ? hi : v); };
+        for (int Y = 0; Y < 256; ++Y) t.yq[Y] = (uint16_t)cl(lround(Y * (242.0 / 255.0)), 0, 242);                  // io_image.hpp:72
+        for (int c = 0; c < 256; ++c) t.cq[c] = (int8_t)cl(lround((c - 128) * (40.0 / 128.0)), -40, 40);           // :73-76
+        for (int q = 0; q <= 242; ++q) t.yd[q] = (uint8_t)cl(lround(q * (255.0 / 242.0)), 0, 255);                  // :81
+        for (int q = -40; q <= 40; ++q) t.cd[q + 40] = (uint8_t)cl(lround(128 + q * (128.0 / 40.0)), 0, 255);       // :82-83
+        HIPCHK(hipMalloc((void**)&d_qt, sizeof t)); HIPCHK(hipMemcpy(d_qt, &t, sizeof t, hipMemcpyHostToDevice));
+    }
+    *out = d_qt; return T3_OK;
+}
+unsigned blocks_for(uint64_t items) { return (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, (items + 255) / 256), 1u << 30); }
+}  // namespace
+
+extern "C" {
+
+int t3hip_rgb_to_quant_dev(const uint8_t* d_rgb, uint64_t n_px, void* d_px6, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!n_px) return T3_OK;
+    if (!d_rgb || !d_px6) return T3_E_ARG;
+    const QuantTables* t; int rc = tables(&t); if (rc) return rc;
+    hipLaunchKernelGGL(rgb_to_quant_kernel, dim3(blocks_for((n_px + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_rgb, n_px, (uint16_t*)d_px6, t);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+int t3hip_quant_to_rgb_dev(const void* d_px6, uint64_t n_px, uint8_t* d_rgb, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!n_px) return T3_OK;
+    if (!d_rgb || !d_px6) return T3_E_ARG;
+    const QuantTables* t; int rc = tables(&t); if (rc) return rc;
+    hipLaunchKernelGGL(quant_to_rgb_kernel, dim3(blocks_for((n_px + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)d_px6, n_px, d_rgb, t);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+int t3hip_rgb_to_quant(const uint8_t* rgb, uint64_t n_px, void* px6) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!n_px) return T3_OK;
+    if (!rgb || !px6) return T3_E_ARG;
+    void *di, *dout; int rc = api_scratch(0, 3 * n_px + 64, &di); if (rc) return rc;
+    rc = api_scratch(1, 6 * n_px + 64, &dout); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(di, rgb, 3 * n_px, hipMemcpyHostToDevice, api_stream()));
+    rc = t3hip_rgb_to_quant_dev((const uint8_t*)di, n_px, dout, api_stream()); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(px6, dout, 6 * n_px, hipMemcpyDeviceToHost, api_stream()));
+    HIPCHK(hipStreamSynchronize(api_stream())); return T3_OK;
+}
+int t3hip_quant_to_rgb(const void* px6, uint64_t n_px, uint8_t* rgb) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!n_px) return T3_OK;
+    if (!rgb || !px6) return T3_E_ARG;
+    void *di, *dout; int rc = api_scratch(0, 6 * n_px + 64, &di); if (rc) return rc;
+    rc = api_scratch(1, 3 * n_px + 64, &dout); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(di, px6, 6 * n_px, hipMemcpyHostToDevice, api_stream()));
+    rc = t3hip_quant_to_rgb_dev(di, n_px, (uint8_t*)dout, api_stream()); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(rgb, dout, 3 * n_px, hipMemcpyDeviceToHost, api_stream()));
+    HIPCHK(hipStreamSynchronize(api_stream())); return T3_OK;
+}
+
+}  // extern "C"

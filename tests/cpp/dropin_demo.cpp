@@ -29,7 +29,16 @@ int main(int argc, char** argv) {
     std::vector<PixelYCbCrQuant> q2; bool ok_decf = decode_frame(proff, q2, df);
     bool same = ok_decf && q2.size() == q.size() && memcmp(q2.data(), q.data(), q.size() * 6) == 0;
 
-    printf("{\"ok_raw\":%d,\"raw_words\":%zu,\"raw_hash\":\"%016llx\",\"ok_enc\":%d,\"enc_words\":%zu,\"enc_hash\":\"%016llx\",\"ok_dec_compat\":%d,"
+    // row f3: S24 subword stream of the raw words, base-243 wire form and back (OLD:834-859, TPACK:28-50)
+    std::vector<UTrit> tr; extract_subword_stream_from_words(raw, 24, tr);
+    std::vector<uint8_t> b243; tpack::ut_to_base243(tr, b243);
+    std::vector<UTrit> tr2; bool ok_b243 = tpack::base243_to_ut(b243, tr2) && tr2 == tr;
+    std::vector<Word27> w24; build_words_from_subword_stream(tr2, 24, w24);
+
+    printf("{\"sub_trits\":%zu,\"sub_hash\":\"%016llx\",\"b243_bytes\":%zu,\"b243_hash\":\"%016llx\",\"ok_b243\":%d,\"w24_hash\":\"%016llx\",",
+           tr.size(), (unsigned long long)fnv(tr.data(), tr.size()), b243.size(), (unsigned long long)fnv(b243.data(), b243.size()), ok_b243 ? 1 : 0,
+           (unsigned long long)fnv(w24.data(), w24.size() * 9));
+    printf("\"ok_raw\":%d,\"raw_words\":%zu,\"raw_hash\":\"%016llx\",\"ok_enc\":%d,\"enc_words\":%zu,\"enc_hash\":\"%016llx\",\"ok_dec_compat\":%d,"
            "\"seen_profile\":%d,\"seen_tile_w\":%d,\"ok_enc_fixed\":%d,\"ok_dec_fixed\":%d,\"roundtrip_equal\":%d,\"selftest_api_roundtrip\":%d,\"status\":%d}\n",
            ok_raw, raw.size(), (unsigned long long)fnv(raw.data(), raw.size() * 9), ok_enc, prof.size(), (unsigned long long)fnv(prof.data(), prof.size() * 9), ok_dec,
            (int)d.cfg_last_seen.profile, (int)d.cfg_last_seen.tile.w, ok_encf, ok_decf, same, selftest_api_roundtrip(), t3::last_status());

@@ -46,3 +46,8 @@ def test_dropin_caller_sequence(gpu, orc, tmp_path):
     if rcd == 0 or seen.profile != ol.make_cfg().profile:
         assert out["seen_profile"] == seen.profile
     assert out["ok_enc_fixed"] == 1 and out["ok_dec_fixed"] == 1 and out["roundtrip_equal"] == 1 and out["selftest_api_roundtrip"] == 1
+    tr = orc.extract_subword_stream(raw, 24)                       # row f3 through the header's reference-named functions
+    b243 = orc.ut_to_base243(tr)
+    assert out["sub_trits"] == len(tr) and out["sub_hash"] == ol.fnv_hex(tr)
+    assert out["b243_bytes"] == len(b243) and out["b243_hash"] == ol.fnv_hex(b243) and out["ok_b243"] == 1
+    assert out["w24_hash"] == ol.fnv_hex(orc.build_words_from_subword_stream(tr, 24, 0))

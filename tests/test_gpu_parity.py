@@ -341,3 +341,30 @@ def test_subword_dev_entry_points_full_frame(t3, orc, gpu):
     assert torch.equal(back[:, :8], w[:, :8]) and torch.equal(back[:, 8], torch.zeros_like(back[:, 8]))   # trits 24..26 dropped
     sample = slice(12345, 12345 + 4096)
     assert np.array_equal(tr[sample.start * N: sample.stop * N].cpu().numpy(), orc.extract_subword_stream(w[sample].cpu().numpy(), N))
+
+
+# ---- RGB8 <-> quantised YCbCr bridge (parity against the oracle's restatement; the reference header
+#      does not compile here, so this row is "parity unpinned" against a reference build) ---------------------------------
+@pytest.mark.gpu
+def test_rgb_bridge_exhaustive(t3, orc, gpu):
+    v = np.arange(1 << 24, dtype=np.uint32)
+    rgb = np.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255], axis=1).astype(np.uint8).reshape(-1)
+    got = t3.rgb_to_quant_stream(rgb)
+    want = orc.rgb_to_quant(rgb)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    names = want.dtype.names
+    assert int(want[names[0]].max()) == 242 and int(want[names[1]].min()) >= -40 and int(want[names[2]].max()) <= 40
+    for n in (0, 1, 2, 3, 5, 1023):                                   # ragged tails of the 4-pixel lanes
+        assert np.array_equal(t3.rgb_to_quant_stream(rgb[: 3 * n]).view(np.uint8), want[:n].view(np.uint8))
+
+
+@pytest.mark.gpu
+def test_rgb_bridge_inverse(t3, orc, gpu):
+    Y, Cb, Cr = np.meshgrid(np.arange(243), np.arange(-40, 41), np.arange(-40, 41), indexing="ij")
+    px = np.zeros(Y.size + 6, ol.PIXEL_DT); names = px.dtype.names
+    px[names[0]][: Y.size] = Y.reshape(-1); px[names[1]][: Y.size] = Cb.reshape(-1); px[names[2]][: Y.size] = Cr.reshape(-1)
+    px[names[0]][Y.size:] = [243, 300, 65535, 0, 100, 242]            # out-of-range values: the clamps decide
+    px[names[1]][Y.size:] = [-41, 41, -32768, 32767, -100, 40]; px[names[2]][Y.size:] = [41, -41, 32767, -32768, 100, -40]
+    assert np.array_equal(t3.quant_stream_to_rgb(px), orc.quant_to_rgb(px))
+    for n in (1, 2, 3, 5):
+        assert np.array_equal(t3.quant_stream_to_rgb(px[1000: 1000 + n]), orc.quant_to_rgb(px[1000: 1000 + n]))
