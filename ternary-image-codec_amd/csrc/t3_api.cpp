@@ -115,11 +115,14 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     uint64_t Lk = 2;
     for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) Lk = Lk / gcd64(Lk, L.band_k[b]) * L.band_k[b];
     uint32_t lut_bytes = lut.bytes;
+    bool mixed = false;
+    { int k0 = 0; for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) { if (!k0) k0 = L.band_k[b]; else if (k0 != L.band_k[b]) mixed = true; } }
     // pick q: tile = 9*Lk*q stream symbols; band b then owns Lk*q/k_b blocks
     double best_score = -1; uint32_t best_q = 0;
     for (int pass = 0; pass < 2 && !best_q; ++pass) {
         const uint32_t budget = pass == 0 ? 53u * 1024u : 160u * 1024u;     // <= 53 KiB: three workgroups per CU
         for (uint32_t q = 1; q <= 4096; ++q) {
+            if (mixed && (q & 1u)) continue;                             // mixed k: even multipliers only (measured: odd ones halve the LUT kernel's speed)
             const uint64_t Lq = Lk * q; if (9 * Lq > 60000) break;
             uint32_t waves = 0, blocks_total = 0, outb = 0;
             for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) {

@@ -250,6 +250,24 @@ __device__ __forceinline__ uint32_t il_perm(uint32_t u, const EncArgs& a) {
     const uint32_t rowlen = min(a.il_w, take - r * a.il_w);
     return base + r * a.il_w + ((r & 1u) ? rowlen - 1u - c : c);
 }
+// The same map for a run of consecutive positions: one pair of divisions at the start, then a few compares per step
+struct IlCursor {
+    uint32_t base, take, rw, c, rowlen, odd;                 // chunk start, chunk size, row start in the chunk, column, row length, row parity
+    __device__ __forceinline__ void init(uint32_t u, const EncArgs& a) {
+        const uint32_t chunk = fdiv(u, a.div_A); base = chunk * a.il_A;
+        const uint32_t rem = u - base; take = min(a.il_A, a.n_sym - base);
+        const uint32_t r = fdiv(rem, a.div_w); rw = r * a.il_w; c = rem - rw; odd = r & 1u;
+        rowlen = min(a.il_w, take - rw);
+    }
+    __device__ __forceinline__ uint32_t get() const { return base + rw + (odd ? rowlen - 1u - c : c); }
+    __device__ __forceinline__ void next(const EncArgs& a) {
+        if (++c == rowlen) {
+            c = 0; rw += a.il_w; odd ^= 1u;
+            if (rw >= take) { base += a.il_A; take = min(a.il_A, a.n_sym - base); rw = 0; odd = 0; }
+            rowlen = min(a.il_w, take - rw);
+        }
+    }
+};
 __device__ __forceinline__ uint32_t il_row_start(uint32_t u, const EncArgs& a) {
     const uint32_t chunk = fdiv(u, a.div_A), base = chunk * a.il_A, rem = u - base;
     return base + fdiv(rem, a.div_w) * a.il_w;
@@ -513,10 +531,12 @@ __device__ __forceinline__ void convert_groups(const EncArgs& a, uint32_t stage,
                     }
                 }
             } else if (live) {
+                IlCursor cur;
+                if constexpr (IL) { if (u0 + q * QS < a.n_sym) cur.init(u0 + q * QS, a); }
 #pragma unroll
                 for (uint32_t i = 0; i < QS; ++i) {
                     uint32_t u = u0 + q * QS + i;
-                    if constexpr (IL) { if (u >= a.n_sym) continue; u = il_perm(u, a); }
+                    if constexpr (IL) { if (u >= a.n_sym) continue; u = cur.get(); cur.next(a); }
                     if (u >= S0 && u < S0 + TS) lds[a.sym_off + (u - S0)] = (uint8_t)(sq[i] << SH);
                 }
             }
