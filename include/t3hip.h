@@ -124,6 +124,11 @@ int  t3hip_gf27_tables(uint8_t* exp78, int16_t* log27, uint8_t* mul729, uint8_t*
 int  t3hip_rs_generator(int k, uint8_t* g_out);
 /* parity = data * P, P is k x (26-k) row-major (row i = parity of unit vector e_i). */
 int  t3hip_rs_parity_matrix(int k, int mode, uint8_t* P_out);
+/* Host only: the tables of the matrix-core encoder for one k, for inspection and CPU tests.
+ * afrag[768]: A operand of v_mfma_i32_32x32x32_i8, 3 K-steps x 64 lanes x 4 dwords (trit coefficients as signed bytes);
+ * lds_img[3168]: three 4-KiB scrambler-state tables (27 symbols x 32 bank copies: trits | scrambled symbol << 24), then
+ * the three 128-byte mod-3 fold tables M_t[x] = 3^t ((x - 64) mod 3). */
+int  t3hip_mfma_encode_tables(int k, int mode, uint32_t* afrag768, uint32_t* lds_img3168);
 /* HeaderCodec::pack / check / unpack (OLD:206-380). */
 int  t3hip_header_pack(const t3_cfg* cfg, uint32_t frame_seq, uint32_t band_map_hash, uint8_t syms27[27]);
 int  t3hip_header_check(const uint8_t syms27[27]);           /* 1 ok, 0 bad */

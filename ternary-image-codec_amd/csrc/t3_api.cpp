@@ -396,6 +396,12 @@ int t3hip_gf27_tables(uint8_t* e78, int16_t* l27, uint8_t* m729, uint8_t* i27) {
     return T3_OK;
 }
 int t3hip_rs_generator(int k, uint8_t* g_out) { if (!valid_k(k) || !g_out) return T3_E_ARG; rs_generator(k, g_out); return T3_OK; }
+int t3hip_mfma_encode_tables(int k, int mode, uint32_t* afrag, uint32_t* lds_img) {
+    if (!valid_k(k) || !afrag || !lds_img || mode < 0 || mode > 1) return T3_E_ARG;
+    std::vector<uint32_t> a, l; build_mfma_encode(k, mode, a, l);
+    memcpy(afrag, a.data(), a.size() * 4); memcpy(lds_img, l.data(), l.size() * 4);
+    return T3_OK;
+}
 int t3hip_rs_parity_matrix(int k, int mode, uint8_t* P) { if (!valid_k(k) || !P || mode < 0 || mode > 1) return T3_E_ARG; rs_parity_matrix(k, mode, P); return T3_OK; }
 int t3hip_header_pack(const t3_cfg* c, uint32_t fs, uint32_t bh, uint8_t s[27]) { if (!c || !s) return T3_E_ARG; header_pack(*c, fs, bh, s); return T3_OK; }
 int t3hip_header_check(const uint8_t s[27]) { return s && header_check(s) ? 1 : 0; }

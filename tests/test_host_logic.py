@@ -149,3 +149,55 @@ def test_device_division_tricks_are_exact():
     want = (v % (1 << 32)) % 81                          # (uint32_t)(Cbq + 40) % 81, as i2tr sees it (OLD:698)
     xx = np.where(v < 0, v + 32854, v)
     assert (xx >= 0).all() and (xx < 65536).all() and (xx % 81 == want).all()
+
+
+def _sb(x):
+    """signed value of a byte"""
+    return x - 256 if x >= 128 else x
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("k", [24, 22, 20, 18])
+def test_mfma_encode_tables_reproduce_the_parity_matrix(t3, orc, k, mode):
+    """CPU emulation of the matrix-core parity path from the host-built tables alone: the A operand times the
+    trit bytes of a block, folded through the M tables, must equal RS parity as the oracle computes it, scrambler included."""
+    r = 26 - k; H = r // 2
+    af = np.zeros(768, np.uint32); img = np.zeros(3168, np.uint32)
+    assert t3.lib().t3hip_mfma_encode_tables(k, mode, af.ctypes.data_as(C.c_void_p), img.ctypes.data_as(C.c_void_p)) == 0
+    A = af.reshape(3, 64, 4)                                      # [step][lane][dword]
+    T = img[: 3 * 1024].reshape(3, 32, 32)[:, :27, 0]             # [state][symbol] (bank copy 0; all copies equal)
+    assert np.array_equal(img[: 3 * 1024].reshape(3, 32, 32)[:, :27, :], np.repeat(T[:, :, None], 32, axis=2))
+    M = img[3 * 1024:].view(np.uint8).reshape(3, 128)
+    rng = np.random.default_rng(k + mode)
+    data = rng.integers(0, 27, (64, k), dtype=np.uint8)
+    want = orc.rs_encode_blocks(k, data, mode)[:, k:]             # unscrambled parity symbols
+    scr_pos = 22 if k == 22 else 20
+    for blk in range(64):
+        st = rng.integers(0, 3, 8)                                # arbitrary scrambler states of the parity symbols
+        acc = np.full((2, 16), 64, np.int64)                      # [lane half hh][accumulator register i]
+        for s in range(3):
+            for kh in range(2):
+                for d in range(4):
+                    p = 8 * s + 4 * kh + d
+                    if p < k:
+                        bdw = int(T[0][data[blk, p]])             # state 0: the symbol's own trits
+                    elif r >= 4 and p in (scr_pos, scr_pos + 1):
+                        j0 = 4 * (p - scr_pos); bdw = sum(int(st[j0 + b]) << (8 * b) for b in range(4) if j0 + b < r)
+                    else:
+                        bdw = 0
+                    bb = [_sb((bdw >> (8 * q)) & 0xFF) for q in range(4)]
+                    for m in range(32):                            # A lane (row m, K-half kh)
+                        adw = int(A[s][m + 32 * kh][d]); hh = (m >> 2) & 1; i = (m & 3) + 4 * (m >> 3)
+                        acc[hh][i] += sum(_sb((adw >> (8 * q)) & 0xFF) * bb[q] for q in range(4))
+        for j in range(r):
+            hh, jj = divmod(j, H)
+            x = [int(acc[hh][3 * jj + t]) + (int(st[j]) if r == 2 else 0) for t in range(3)]
+            assert all(0 <= v < 128 for v in x)
+            sym = int(M[0][x[0]]) + int(M[1][x[1]]) + int(M[2][x[2]])
+            tr = [(int(want[blk, j]) // 3 ** t) % 3 for t in range(3)]
+            assert sym == sum(((tr[t] + int(st[j])) % 3) * 3 ** t for t in range(3)), (k, mode, blk, j)
+    for v in range(3):                                             # T: signed trits + scrambled image
+        for d in range(27):
+            e = int(T[v][d]); tr = [d % 3, (d // 3) % 3, d // 9]
+            assert [_sb((e >> (8 * q)) & 0xFF) for q in range(3)] == [(-1 if t == 2 else t) for t in tr]
+            assert e >> 24 == sum(((tr[t] + v) % 3) * 3 ** t for t in range(3))
