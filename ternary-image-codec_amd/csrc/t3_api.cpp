@@ -124,16 +124,15 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
         for (uint32_t q = 1; q <= 4096; ++q) {
             if (mixed && (q & 1u)) continue;                             // mixed k: even multipliers only (measured: odd ones halve the LUT kernel's speed)
             const uint64_t Lq = Lk * q; if (9 * Lq > 60000) break;
-            uint32_t waves = 0, blocks_total = 0, outb = 0;
+            uint32_t waves = 0, blocks_total = 0;
             for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) {
                 const uint32_t nb = (uint32_t)(Lq / L.band_k[b]);
-                blocks_total += nb; outb += round16(26 * nb + 32);
+                blocks_total += nb;
             }
             waves = (blocks_total + 63) / 64;                          // lanes are dealt to blocks linearly across bands
             if (waves > (pass == 0 ? 8u : (uint32_t)kMaxWaves)) break;   // pass 0: 512-thread workgroups, three per CU
             const uint32_t groups = (uint32_t)(9 * Lq / GS) + 6, stage = groups * GB + 1024 + 32;   // +1 KiB: LDS-DMA pieces are whole
             const uint32_t total = kLdsHdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq)) + kSymBack + (L.interleave2d ? 1u : 2u) * round16(stage);
-            (void)outb;
             if (total > budget) break;
             // wave-instructions per stream symbol: phase 2 costs ~180 per wave, phase 1 (pixels) ~120 per wave-iteration
             const uint32_t wpp = p1_waves_per_parity((uint32_t)(9 * Lq));
@@ -150,14 +149,14 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     off += kSymFront; a.sym_off = off; off += round16(9 * Lq) + kSymBack;   // slack either side: phase 1 writes whole pixel triples
     a.stage_off = off;
     a.stage_groups = 9 * Lq / GS + 6;
-    uint32_t outb = 0, nw = 0, n_tiles = 0;
+    uint32_t nw = 0, n_tiles = 0;
     for (int b = 0; b < 9; ++b) {
         a.band_k[b] = L.band_k[b]; a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b];
         a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6);
         a.band_lut_off[b] = kLdsHdr + lut.k_off[k_index(L.band_k[b])];
         if (!(band_mask >> b & 1)) { a.band_nb_tile[b] = 0; a.band_blocks[b] = 0; continue; }
         const uint32_t nb = Lq / L.band_k[b];
-        a.band_nb_tile[b] = nb; a.band_out_off[b] = outb; outb += round16(26 * nb + 32);
+        a.band_nb_tile[b] = nb;
         nw += nb;
         n_tiles = std::max<uint32_t>(n_tiles, (uint32_t)((L.band_blocks[b] + nb - 1) / nb));
     }

@@ -4,15 +4,16 @@
 // decode_block OLD:546-662 with the Forney sign fixed), the i%9 re-merge the reference omits, symbols -> 26-trit words
 // (OLD:1022-1040) and unpack_two_pixels (OLD:706-722).  Everything else goes through the generic kernels in t3_decode.hip.
 //
-// One lane = one RS block; wave w = band w.  Per tile:
+// One lane = one RS block, blocks dealt linearly over the eight waves.  Per tile:
 //   D1  7 aligned dword loads per lane (blocks are 26 B, 2-byte aligned) -> 26 symbols in registers
 //   D2  descramble through an 81-byte LDS table (result pre-scaled by 8), syndromes through a per-position LUT:
 //       6-bit SWAR trit fields, two conflict-free ds_read_b64 per symbol, one mod-3 fold per block
-//   D3  lanes with non-zero syndromes: Berlekamp–Massey (x*B kept shifted, fixed 8-coefficient registers), degree test,
-//       Chien over the 26 positions, Forney; field products/sums through 729-byte LDS tables
-//   D4  data symbols -> stream order in LDS (byte 9(mk+p)+b), <=3 corrected bytes patched in place
-//   D5  13 symbols -> 3 pixels (two triples per lane with packed 16-bit ops) or 26 symbols -> 3 words, staged in LDS,
-//       copied out with 16-byte coalesced stores.
+//   D3  lanes with non-zero syndromes: Berlekamp-Massey (x*B kept shifted, fixed 8-coefficient registers) on a fused
+//       multiply-add table (a + x y, 27^3 bytes in LDS), degree test, Chien search by table (root mask per locator,
+//       global memory), Forney
+//   D4  data symbols -> stream order in LDS (byte 9(mk+p)+b), <=t corrected bytes patched in place
+//   D5  pixels: one lane = four triples, 13 aligned dwords of symbols -> 12 pixels with packed 16-bit ops -> 72 bytes stored
+//       straight to memory;  raw words: 26 symbols -> 3 words, staged in LDS, copied out with 16-byte coalesced stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -133,7 +134,7 @@ __device__ __forceinline__ Row row(uint32_t b) { return *(const Row*)(lds + 16u 
 template <int R, bool TO_PIXELS>
 __global__ __launch_bounds__(512, 4) void decode_fixed_kernel(const DecFxArgs a) {
     constexpr uint32_t K = 26 - R, SLAB = R == 8 ? 768u : 512u;
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     // constants -> LDS
     if (tid == 0) {
 #pragma unroll

@@ -35,7 +35,6 @@ struct EncArgs {
     uint32_t  band_nb_tile[9];      // blocks per tile
     uint32_t  band_blocks[9];       // blocks in the frame
     uint32_t  band_lut_off[9];      // LDS byte offset of the band's LUT
-    uint32_t  band_out_off[9];      // byte offset of the band's staging run inside the current stage buffer (16-B aligned, slack)
     uint32_t  band_boff6[9];        // (band_body_off + 4) % 6 : scrambler cycle phase of the band's first symbol
     uint64_t  band_body_off[9];
     uint32_t  band_first[10];       // phase-2 work item -> band: band b owns items [band_first[b], band_first[b+1]); one lane = one block

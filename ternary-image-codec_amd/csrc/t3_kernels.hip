@@ -149,7 +149,7 @@ template <> struct LutGeo<6> { static constexpr uint32_t SLAB = 1024, VOFF = 256
 template <> struct LutGeo<8> { static constexpr uint32_t SLAB = 1280, VOFF = 512; };
 
 struct Blk26 { uint32_t w[7]; };   // 26 output bytes, little-endian packed (w[6] holds 2)
-struct BandRow { uint32_t k, nbt, blocks, lut_off, out_off, boff6; uint64_t body_off; };   // 32 B, LDS header row b
+struct BandRow { uint32_t k, nbt, blocks, lut_off, pad_, boff6; uint64_t body_off; };   // 32 B, LDS header row b
 __device__ __forceinline__ BandRow band_row(uint32_t b) { return *(const BandRow*)(lds + 32u * b); }
 __device__ __forceinline__ uint32_t band_first(uint32_t b) { return *(const uint32_t*)(lds + 288u + 4u * b); }
 
@@ -678,7 +678,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 #pragma unroll
         for (int b = 0; b < 9; ++b) {
             BandRow r; r.k = a.band_k[b]; r.nbt = a.band_nb_tile[b]; r.blocks = a.band_blocks[b]; r.lut_off = a.band_lut_off[b];
-            r.out_off = 0; r.boff6 = a.band_boff6[b]; r.body_off = a.band_body_off[b];
+            r.pad_ = 0; r.boff6 = a.band_boff6[b]; r.body_off = a.band_body_off[b];
             *(BandRow*)(lds + 32 * b) = r;
         }
 #pragma unroll
