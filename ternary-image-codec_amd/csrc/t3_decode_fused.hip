@@ -23,14 +23,19 @@
 namespace t3 {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+// LDS access by absolute byte address in the hot loops: the kernel owns the whole LDS allocation (no static __shared__), so
+// the dynamic array starts at 0; `lds[x]` would make the compiler add that link-time zero to every address (t3_kernels.hip).
+#define T3_LP(T, a) ((__attribute__((address_space(3))) T*)(uintptr_t)(a))
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t l8(uint32_t a) { return *T3_LP(const uint8_t, a); }
 
 namespace {
 constexpr uint32_t MUL = kFxTab, ADD = kFxTab + 729, SUB = kFxTab + 1458, INV = kFxTab + 2187, NEG = INV + 27, EXP = NEG + 27, DSC = EXP + 26;
 static_assert(DSC == kFxTab + offsetof(FxTables, descr), "LDS table map");
 
-__device__ __forceinline__ uint32_t gfm(uint32_t a, uint32_t b) { return lds[MUL + a * 27u + b]; }
-__device__ __forceinline__ uint32_t gfa(uint32_t a, uint32_t b) { return lds[ADD + a * 27u + b]; }
-__device__ __forceinline__ uint32_t gfs(uint32_t a, uint32_t b) { return lds[SUB + a * 27u + b]; }
+__device__ __forceinline__ uint32_t gfm(uint32_t a, uint32_t b) { return l8(MUL + a * 27u + b); }
+__device__ __forceinline__ uint32_t gfa(uint32_t a, uint32_t b) { return l8(ADD + a * 27u + b); }
+__device__ __forceinline__ uint32_t gfs(uint32_t a, uint32_t b) { return l8(SUB + a * 27u + b); }
 
 __device__ __forceinline__ uint32_t mod3x5(uint32_t x) {          // five 6-bit fields (<= 63) -> {0,1,2}
     x = (x & 0x030C30C3u) + ((x >> 2) & 0x0F3CF3CFu);
@@ -50,7 +55,7 @@ struct Fix { uint32_t np; uint32_t pos[4]; uint32_t mag[4]; };   // up to t = 4 
 // Horner loops start at the true degree).  Returns false for an uncorrectable block.
 template <int R>
 __device__ __forceinline__ bool fx_correct(const uint32_t* S, Fix& fx, const uint32_t* __restrict__ root_tbl, uint32_t FMA) {
-    auto fma = [FMA](uint32_t acc, uint32_t x, uint32_t y) -> uint32_t { return lds[FMA + (x * 27u + y) * 27u + acc]; };   // acc + x y
+    auto fma = [FMA](uint32_t acc, uint32_t x, uint32_t y) -> uint32_t { return l8(FMA + (x * 27u + y) * 27u + acc); };   // acc + x y
     constexpr int T = R / 2, NP = R + 2;
     uint32_t sg[NP], bx[NP];                                        // sigma, and x^m * B (B shifted as the reference's xmdB)
 #pragma unroll
@@ -63,7 +68,7 @@ __device__ __forceinline__ bool fx_correct(const uint32_t* S, Fix& fx, const uin
 #pragma unroll
         for (int i = 1; i <= n; ++i) d = fma(d, sg[i], S[n - i]);           // sigma[i] = 0 beyond L: same sum as OLD:572
         const bool upd = d != 0 && 2u * L <= (uint32_t)n;
-        const uint32_t iv = lds[INV + d], nd = lds[NEG + d];
+        const uint32_t iv = l8(INV + d), nd = l8(NEG + d);
         uint32_t nb[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -108,14 +113,14 @@ __device__ __forceinline__ bool fx_correct(const uint32_t* S, Fix& fx, const uin
     for (int e = 0; e < T; ++e) {
         if ((uint32_t)e < np) {
             const uint32_t p = (uint32_t)__ffs((int)r) - 1u; r &= r - 1u;
-            const uint32_t xi = lds[EXP + (p == 0 ? 0u : 26u - p)];
+            const uint32_t xi = l8(EXP + (p == 0 ? 0u : 26u - p));
             uint32_t num = Om[R - 1];
 #pragma unroll
             for (int q = R - 2; q >= 0; --q) num = fma(Om[q], num, xi);
             uint32_t den = fma(sg[1], gfa(sg[2], sg[2]), xi);                  // sigma1 + 2 sigma2 x  (x^2 term of sigma' is 3 sigma3 = 0)
             if constexpr (T >= 4) den = fma(den, gfm(gfm(sg[4], xi), xi), xi);  // + 4 sigma4 x^3 = sigma4 x^3
             if (den == 0) return false;                                        // OLD:656
-            fx.pos[e] = p; fx.mag[e] = gfm(lds[NEG + num], lds[INV + den]);    // OLD:657; FIXED subtracts it
+            fx.pos[e] = p; fx.mag[e] = gfm(l8(NEG + num), l8(INV + den));    // OLD:657; FIXED subtracts it
         }
     }
     fx.np = np;
@@ -192,15 +197,15 @@ __global__ __launch_bounds__(512, 4) void decode_fixed_kernel(const DecFxArgs a)
                 for (int i = 0; i < 26; ++i) {
                     uint32_t base = dbase[i % 6];
                     if (i < 2 && first) base = DSC + 32u * (i == 0 ? a.pre0 : a.pre1);
-                    d8[i] = lds[base + c[i]];                                      // descrambled symbol * 8
+                    d8[i] = l8(base + c[i]);                                      // descrambled symbol * 8
                 }
                 uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0;
 #pragma unroll
                 for (uint32_t i = 0; i < 26; ++i) {
-                    const uint2 A = *(const uint2*)(lds + kFxLut + i * SLAB + d8[i]);
-                    const uint2 B = *(const uint2*)(lds + kFxLut + i * SLAB + 256u + d8[i]);
+                    const u32x2 A = *T3_LP(const u32x2, kFxLut + i * SLAB + d8[i]);
+                    const u32x2 B = *T3_LP(const u32x2, kFxLut + i * SLAB + 256u + d8[i]);
                     acc0 += A.x; acc1 += A.y; acc2 += B.x; acc3 += B.y;
-                    if constexpr (R == 8) acc4 += *(const uint32_t*)(lds + kFxLut + i * SLAB + 512u + d8[i]);
+                    if constexpr (R == 8) acc4 += *T3_LP(const uint32_t, kFxLut + i * SLAB + 512u + d8[i]);
                     if (i % 9 == 8) { asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "+v"(acc4)); __builtin_amdgcn_sched_barrier(0); }
                 }
                 const uint32_t x0 = mod3x5(acc0), x1 = mod3x5(acc1), x2 = mod3x5(acc2);
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(512, 4) void decode_fixed_kernel(const DecFxArgs a)
                 // data symbols -> stream order (the zero padding of a band's last block is not stored)
                 const uint32_t yb = a.y_off + b + 9u * K * m;
 #pragma unroll
-                for (uint32_t p = 0; p < K; ++p) lds[yb + 9u * p] = (uint8_t)(d8[p] >> 3);
+                for (uint32_t p = 0; p < K; ++p) *T3_LP(uint8_t, yb + 9u * p) = (uint8_t)(d8[p] >> 3);
 #ifdef T3_ABL_DEC_NO_CORRECT
                 if (any == 0x7FFFFFFFu) {
 #else
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(512, 4) void decode_fixed_kernel(const DecFxArgs a)
                     else {
 #pragma unroll
                         for (int e = 0; e < R / 2; ++e)
-                            if ((uint32_t)e < fx.np && fx.pos[e] < K) { const uint32_t ad = yb + 9u * fx.pos[e]; lds[ad] = (uint8_t)gfs(lds[ad], fx.mag[e]); }
+                            if ((uint32_t)e < fx.np && fx.pos[e] < K) { const uint32_t ad = yb + 9u * fx.pos[e]; *T3_LP(uint8_t, ad) = (uint8_t)gfs(l8(ad), fx.mag[e]); }
                     }
                 }
             }
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(512, 4) void decode_fixed_kernel(const DecFxArgs a)
             for (uint32_t j = tid; 4u * j < ntr; j += nthr) {
                 uint32_t D[13];
 #pragma unroll
-                for (int i = 0; i < 13; ++i) D[i] = *(const uint32_t*)(lds + a.y_off + 52u * j + 4u * i);
+                for (int i = 0; i < 13; ++i) D[i] = *T3_LP(const uint32_t, a.y_off + 52u * j + 4u * i);
                 uint32_t o[18];
 #pragma unroll
                 for (uint32_t pair = 0; pair < 2; ++pair) {                         // pair 0 = triples (0, 2), pair 1 = triples (1, 3)
