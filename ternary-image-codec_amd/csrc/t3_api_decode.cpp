@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/t3hip.h"
@@ -32,9 +33,13 @@ uint32_t* d_roots[4] = {nullptr, nullptr, nullptr, nullptr};   // per k index: t
 int k_index(int k) { return k == 24 ? 0 : k == 22 ? 1 : k == 20 ? 2 : k == 18 ? 3 : -1; }
 
 // Fused FIXED decode (t3_decode_fused.hip): uniform k, 1-D, no beacon.  Returns T3_OK after launching, or 1 if not applicable.
+std::mutex g_tab_mu;   // the lazily built device tables below are shared by every caller thread
+std::recursive_mutex g_mail_mu;   // ... and so are the pinned host mailboxes of the synchronous entry points
+
 int decode_fixed_fused(const void* d_in, uint64_t n_in, const t3_cfg& cfg, const t3_layout& L, const ScrCycle& sc,
                        void* d_out, uint64_t units, int to_pixels, uint32_t* d_fail, hipStream_t s) {
     if (L.beacon_on || L.interleave2d || L.n_raw_words == 0) return 1;
+    std::lock_guard<std::mutex> lk(g_tab_mu);
     for (int b = 1; b < 9; ++b) if (L.band_k[b] != L.band_k[0]) return 1;
     const int k = L.band_k[0], ki = k_index(k);
     if (!d_synd_lut[ki]) {
@@ -156,6 +161,7 @@ int read_header(const void* d_in, uint64_t n_in, int mode, t3_cfg* seen, uint64_
     const uint64_t hw = mode == T3_MODE_FIXED ? 10 : 6;
     if (n_in < hw) return T3_E_HEADER;                                     // OLD:920
     // pinned mailbox: the 54/90 header bytes come back by a real asynchronous DMA (a pageable target costs a staging copy)
+    std::lock_guard<std::recursive_mutex> lk(g_mail_mu);
     static uint8_t* h = nullptr;
     if (!h) HIPCHK(hipHostMalloc((void**)&h, 128, hipHostMallocDefault));
     HIPCHK(hipMemcpyAsync(h, d_in, hw * 9, hipMemcpyDeviceToHost, s));
@@ -227,6 +233,7 @@ int t3hip_decode_profile_dev(const void* d_in, uint64_t n_in, t3_cfg* seen, void
     if (rc) return rc;
     // failure counter in mapped pinned host memory: written only by lanes that give up on a block, read after the sync
     // without a copy (the previous synchronous call has drained, so the host may clear it directly)
+    std::lock_guard<std::recursive_mutex> lk(g_mail_mu);
     static uint32_t* h_flag = nullptr; static uint32_t* d_flag_map = nullptr;
     if (!h_flag) {
         HIPCHK(hipHostMalloc((void**)&h_flag, 64, hipHostMallocMapped));

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "../../include/t3hip.h"
 #include "t3_rgb.h"
@@ -18,7 +19,9 @@ using namespace t3;
 
 namespace {
 QuantTables* d_qt = nullptr;
+std::mutex g_qt_mu;
 int tables(const QuantTables** out) {
+    std::lock_guard<std::mutex> lk(g_qt_mu);
     if (!d_qt) {
         QuantTables t; memset(&t, 0, sizeof t);
         auto cl = [](long v, long lo, long hi) { return v < lo ? lo : (v > hi ? hi : v); };
