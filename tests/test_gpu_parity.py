@@ -368,3 +368,32 @@ def test_rgb_bridge_inverse(t3, orc, gpu):
     assert np.array_equal(t3.quant_stream_to_rgb(px), orc.quant_to_rgb(px))
     for n in (1, 2, 3, 5):
         assert np.array_equal(t3.quant_stream_to_rgb(px[1000: 1000 + n]), orc.quant_to_rgb(px[1000: 1000 + n]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_encode_frame_random_configurations(gpu, orc, mode):
+    """Seeded fuzz over the configuration space (all four codes per band, 1-D / 2-D with odd tile shapes, beacons, seeds)
+    and over pixel counts around the kernels' tile sizes (a single-k tile is 9 * 55 * k symbols ~ 2285 / 2057 / 2513 / 2742 px)."""
+    rng = np.random.default_rng(2024 + mode)
+    edge = [2284, 2285, 2286, 2 * 2285 - 1, 3 * 2285 + 1, 2056, 2057, 2513, 2742, 13 * 2285, 25 * 2285 + 7]
+    for trial in range(28):
+        uniform = trial % 2 == 0
+        uep = int(rng.integers(0, 4)) if uniform else [int(x) for x in rng.integers(0, 4, 9)]
+        two_d = trial % 3 == 0
+        kw = dict(profile=4 if two_d else int(rng.integers(0, 4)), uep=uep,
+                  tile=(int(rng.integers(1, 200)), int(rng.integers(1, 40))) if two_d else (0, 0),
+                  seed=(int(rng.integers(0, 2 ** 32)), int(rng.integers(0, 2 ** 32)), int(rng.integers(0, 2 ** 32))))
+        if trial % 5 == 4:
+            kw["beacon"] = (int(rng.integers(2, 300)), int(rng.integers(0, 9)), 1)
+        cfg, ocfg = both(gpu, kw, mode)
+        n = int(edge[trial % len(edge)] + (rng.integers(-3, 4) if trial >= len(edge) else 0)) if trial % 4 else int(rng.integers(0, 90000))
+        px = rand_pixels(rng, n, in_range=bool(trial % 7))
+        ok, enc = gpu.encode_frame(px, cfg)
+        rc, want = orc.encode_frame(px, ocfg, cap=n + 64)
+        assert ok and rc == 0 and enc.shape == want.shape, (trial, kw, n)
+        assert np.array_equal(enc, want), (trial, kw, n, np.flatnonzero(enc.reshape(-1) != want.reshape(-1))[:10])
+        if mode == 1:                       # FIXED streams decode back to the pixels (odd counts come back padded by one zero pixel)
+            okd, back = gpu.decode_frame(enc, gpu.DecoderContext(mode=1))
+            red = orc.unpack_words(orc.pack_pixels(px))          # what survives the trit packing of out-of-range values
+            assert okd and np.array_equal(back[: len(red)].view(np.uint8), red.view(np.uint8)), (trial, kw, n)
