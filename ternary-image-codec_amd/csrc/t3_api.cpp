@@ -115,6 +115,9 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     uint64_t Lk = 2;
     for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) Lk = Lk / gcd64(Lk, L.band_k[b]) * L.band_k[b];
     uint32_t lut_bytes = lut.bytes;
+    // 2-D through the pipelined flow: a tile's input then covers the row segments it overlaps (up to w - 1 extra symbols each side)
+    const bool il_async = L.interleave2d && fe == FE_PIXELS && cfg.tile_w <= 512;
+    const uint32_t il_extra = il_async ? 2u * cfg.tile_w : 0u;
     bool mixed = false;
     { int k0 = 0; for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) { if (!k0) k0 = L.band_k[b]; else if (k0 != L.band_k[b]) mixed = true; } }
     // pick q: tile = 9*Lk*q stream symbols; band b then owns Lk*q/k_b blocks
@@ -131,11 +134,11 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
             }
             waves = (blocks_total + 63) / 64;                          // lanes are dealt to blocks linearly across bands
             if (waves > (pass == 0 ? 8u : (uint32_t)kMaxWaves)) break;   // pass 0: 512-thread workgroups, three per CU
-            const uint32_t groups = (uint32_t)(9 * Lq / GS) + 6, stage = groups * GB + 1024 + 32;   // +1 KiB: LDS-DMA pieces are whole
-            const uint32_t total = kLdsHdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq)) + kSymBack + (L.interleave2d ? 1u : 2u) * round16(stage);
+            const uint32_t groups = (uint32_t)((9 * Lq + il_extra) / GS) + 8, stage = groups * GB + 1024 + 32;   // +1 KiB: LDS-DMA pieces are whole
+            const uint32_t total = kLdsHdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq) + il_extra) + kSymBack + ((L.interleave2d && !il_async) ? 1u : 2u) * round16(stage);
             if (total > budget) break;
             // wave-instructions per stream symbol: phase 2 costs ~180 per wave, phase 1 (pixels) ~120 per wave-iteration
-            const uint32_t wpp = p1_waves_per_parity((uint32_t)(9 * Lq));
+            const uint32_t wpp = p1_waves_per_parity((uint32_t)(9 * Lq) + il_extra);
             if (fe == FE_PIXELS && wpp > std::max(waves, 4u)) continue;
             const double cost = (180.0 * waves + (fe == FE_PIXELS ? 220.0 * wpp : 180.0 * waves)) / (double)(9 * Lq);
             const double score = 1.0 / cost + 1e-9 * (double)Lq;
@@ -146,9 +149,9 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     const uint32_t Lq = (uint32_t)(Lk * best_q);
     a.Lq = Lq; a.lut_bytes = round16(lut_bytes);
     uint32_t off = kLdsHdr + a.lut_bytes;
-    off += kSymFront; a.sym_off = off; off += round16(9 * Lq) + kSymBack;   // slack either side: phase 1 writes whole pixel triples
+    off += kSymFront; a.sym_off = off; off += round16(9 * Lq + il_extra) + kSymBack;   // slack either side: phase 1 writes whole pixel triples
     a.stage_off = off;
-    a.stage_groups = 9 * Lq / GS + 6;
+    a.stage_groups = (9 * Lq + il_extra) / GS + 8;
     uint32_t nw = 0, n_tiles = 0;
     for (int b = 0; b < 9; ++b) {
         a.band_k[b] = L.band_k[b]; a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b];
@@ -163,7 +166,8 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     a.n_items = nw; a.n_tiles = n_tiles;
     { uint32_t acc = 0; for (int b = 0; b < 9; ++b) { a.band_first[b] = acc; acc += a.band_nb_tile[b]; } a.band_first[9] = acc; }
     a.stage_stride = round16(a.stage_groups * GB + 1024 + 32);
-    a.lds_bytes = a.stage_off + (L.interleave2d ? 1u : 2u) * a.stage_stride;   // 1-D: two stage buffers (the next tile streams in early)
+    a.lds_bytes = a.stage_off + ((L.interleave2d && !il_async) ? 1u : 2u) * a.stage_stride;   // pipelined flow: two stage buffers (the next tile streams in early)
+    a.il_async = il_async ? 1u : 0u;
     a.n_sym = (uint32_t)L.n_sym;
     const ScrCycle sc = scrambler_cycle(cfg.seed_a, cfg.seed_b, cfg.seed_s0);
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
@@ -175,7 +179,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
         a.div_A = to_dev(fastdiv(a.il_A)); a.div_w = to_dev(fastdiv(a.il_w));
     }
     out.block = 64u * std::max<uint32_t>((nw + 63) / 64, 4u);
-    a.p1_wpp = p1_waves_per_parity(9 * Lq);
+    a.p1_wpp = p1_waves_per_parity(9 * Lq + il_extra);
     out.rsel = 0;
     { int k0 = 0; bool same = true; for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) { if (!k0) k0 = L.band_k[b]; else if (k0 != L.band_k[b]) same = false; } if (same && k0 && band_mask == 0x1FF) out.rsel = 26 - k0; }
     a.nb_uniform = out.rsel ? a.band_nb_tile[0] : 0u; a.div_nb = to_dev(fastdiv(a.nb_uniform ? a.nb_uniform : 1u));

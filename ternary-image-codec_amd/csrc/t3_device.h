@@ -47,6 +47,7 @@ struct EncArgs {
     uint32_t  cyc24; uint32_t pre0, pre1;      // scrambler: 6-periodic tail as 2-bit fields (x2), two pre-period states
     uint32_t  scr[12];              // single-k launches: scrambler dwords of the parity symbols per phase (mfma_scrambler_table)
     uint32_t  il_on, il_w, il_A;    // 2-D boustrophedon: row width, chunk area (clamped to n_sym)
+    uint32_t  il_async;             // 2-D through the pipelined flow (pixels, moderate row width): symbol and stage buffers sized for the rows a tile overlaps
     DevDiv    div_A, div_w;
     uint32_t  hdr_syms; uint32_t pad_bytes;    // header symbols; zero bytes after the last symbol (OLD:1164-1167)
     uint64_t  out_syms;

@@ -285,13 +285,13 @@ __device__ __forceinline__ uint32_t il_row_end(uint32_t u, const EncArgs& a) {  
 // neighbour blocks, no LDS staging.  Consecutive lanes hold consecutive blocks, so a wave's seven store instructions
 // cover one contiguous 1664-byte run (13 cache lines).
 template <int R, bool FIXED_LUT>
-__device__ __forceinline__ bool phase2_band(const EncArgs& a, uint32_t tile, uint32_t b, uint32_t m, uint32_t nbt) {
+__device__ __forceinline__ bool phase2_band(const EncArgs& a, uint32_t symb, uint32_t tile, uint32_t b, uint32_t m, uint32_t nbt) {
     constexpr uint32_t K = 26 - R;
     const uint32_t mg = tile * nbt + m;
     const BandRow r = band_row(b);
     if (!(m < nbt && mg < r.blocks)) return false;
     const uint32_t c0 = (r.boff6 + 2u * (mg % 3u)) % 6u;                             // 26 == 2 (mod 6)
-    const Blk26 o = encode_block<R, FIXED_LUT>(a.sym_off + b + 9u * K * m, r.lut_off, c0, r.body_off == 0 && mg == 0, a);
+    const Blk26 o = encode_block<R, FIXED_LUT>(symb + b + 9u * K * m, r.lut_off, c0, r.body_off == 0 && mg == 0, a);
     uint8_t* G = a.body_out + r.body_off + 26ull * mg;
     const bool al = ((uint32_t)(uintptr_t)G & 2u) == 0;
     uint32_t* base = (uint32_t*)(G + (al ? 0 : 2));                                    // six aligned dwords
@@ -320,7 +320,7 @@ struct __attribute__((packed, aligned(2))) U128a2 { uint32_t v[4]; };
 constexpr uint32_t kMfmaModOff = 3 * 4096, kMfmaScr = 336;     // must match t3_host.hpp; scrambler dwords sit in the LDS header
 
 template <int R>
-__device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t tile, uint32_t wave, uint32_t lane, const v4i (&Afr)[3]) {
+__device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t symb, uint32_t tile, uint32_t wave, uint32_t lane, const v4i (&Afr)[3]) {
     constexpr uint32_t K = 26 - R, H = R / 2;
     constexpr uint32_t TB = kLdsHdr, MB = kLdsHdr + kMfmaModOff;
     const uint32_t n = lane & 31u, h = lane >> 5;
@@ -345,7 +345,7 @@ __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t tile,
         uint32_t vb[6];                                                       // table base per position class: state (4 KiB apart), own bank copy
 #pragma unroll
         for (uint32_t q = 0; q < 6; ++q) vb[q] = (((cycs >> (2u * q)) & 3u) << 12) | (TB + 4u * n);
-        const uint32_t sa = a.sym_off + b + 9u * K * m + 36u * h;
+        const uint32_t sa = symb + b + 9u * K * m + 36u * h;
         s.dd0 = 0; s.dd1 = 0;
 #pragma unroll
         for (uint32_t st = 0; st < 3; ++st) {
@@ -578,10 +578,13 @@ __device__ __forceinline__ void px3x2_to_sym13x8(const u16x2* c, u16x2* s) {
 // output thirteen aligned dwords.  Triples 0 and 2 share registers as low/high halves, so do 1 and 3 (same parity each).
 // Triples are written whole: the symbol buffer has kSymFront bytes of slack in front and 64 behind, which take the symbols of
 // the first/last triples that belong to the neighbouring tiles (and of the up to three triples past the tile's last one).
+// Symbols [u_lo, u_hi) are produced (1-D: the tile itself; pipelined 2-D: the row segments it overlaps); symbol u lands at
+// LDS byte sym_off + (u - u_lo).
 template <int SC>
-__device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, uint32_t stage, uint64_t b0, uint32_t S0, uint32_t TS,
+__device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, uint32_t stage, uint64_t b0, uint32_t u_lo, uint32_t u_hi,
                                                       uint32_t lane, uint32_t wave, uint32_t nwv) {
-    const uint32_t t_base = (S0 / 13u) & ~3u, t_end = (S0 + TS + 12u) / 13u;     // triples [t_base, t_end) touch the tile
+    const uint32_t S0 = u_lo;
+    const uint32_t t_base = (u_lo / 13u) & ~3u, t_end = (u_hi + 12u) / 13u;       // triples [t_base, t_end) cover them
     const uint32_t nw1 = min(a.p1_wpp, nwv);                                      // waves that convert (planner: just enough lanes)
     if (wave >= nw1) return;
     for (uint32_t e0 = wave * 64u; t_base + 4u * e0 < t_end; e0 += nw1 * 64u) {
@@ -713,15 +716,24 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     // first lane group whose input a tile starting at stream symbol S needs (pixels: the packed converter starts at a
     // multiple of 4 triples = 2 groups)
     auto first_group = [](uint32_t S) -> uint32_t { return FE == FE_PIXELS ? ((S / 13u) & ~3u) / 2u : S / GS; };
-    if constexpr (!IL) {                                                     // prologue: first tile's input
-        if (blockIdx.x < a.n_tiles) stage_input<FE>(a, a.stage_off, first_group(blockIdx.x * TS), (blockIdx.x * TS + TS + GS - 1u) / GS, lane, wave, nwv);
+    // pre-interleave symbols [lo, hi) a tile starting at S needs: itself in 1-D; in 2-D the whole row segments it overlaps
+    // (the map stays inside a row segment, OLD:750-780) plus its own positions past the end of the stream (identity)
+    auto need_lo = [&](uint32_t S) -> uint32_t { return (IL && S < a.n_sym) ? il_row_start(S, a) : S; };
+    auto need_hi = [&](uint32_t S) -> uint32_t { return (IL && S < a.n_sym) ? max(il_row_end(min(S + TS, a.n_sym) - 1u, a), S + TS) : S + TS; };
+    // pipelined flow (input prefetch, packed converter): always in 1-D; in 2-D when the planner could afford it (il_async):
+    // phase 1 then leaves the symbols in PRE-interleave order and a permutation pass moves them, in post-interleave order,
+    // into the stage buffer the tile's input has just been consumed from
+    const bool fast = !IL || a.il_async != 0;
+    if (fast) {                                                              // prologue: first tile's input
+        const uint32_t S = blockIdx.x * TS;
+        if (blockIdx.x < a.n_tiles) stage_input<FE>(a, a.stage_off, first_group(need_lo(S)), (need_hi(S) + GS - 1u) / GS, lane, wave, nwv);
     }
     uint32_t younger = 0;                                                    // VMEM ops this wave issued after its last prefetch
     // Tiles are handed out dynamically: the three workgroups of a CU progress at different speeds (oldest wave first),
     // up to 1.6x apart.  The first tile is blockIdx.x, every further one a ticket.  One counter serves ~11 ns per draw
     // (memory-side atomic), too slow for 14k tiles, so workgroups and tiles are split into n_classes classes by index
     // modulo n_classes, each with its own counter (class == XCD under round-robin dispatch, but nothing relies on it).
-    const bool dyn = !IL && a.tile_ctr != nullptr;
+    const bool dyn = fast && a.tile_ctr != nullptr;
     const uint32_t NC = a.n_classes, cls = blockIdx.x % NC;
     uint32_t* const ctr = a.tile_ctr + 64u * cls;                              // one counter per class, 256 B apart
     const uint32_t wgc = (gridDim.x - cls + NC - 1u) / NC;                     // workgroups in this class
@@ -734,20 +746,22 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     uint32_t par = 0;
     for (uint32_t tile = blockIdx.x, nxt = dyn ? cls + NC * (wgc + blockIdx.x / NC) : blockIdx.x + gridDim.x, nn = 0; tile < a.n_tiles; tile = nxt, nxt = nn, par ^= 1u) {
         const uint32_t S0 = tile * TS;
-        const uint32_t stage = a.stage_off + (IL ? 0u : par * a.stage_stride);
+        const uint32_t stage = a.stage_off + (fast ? par * a.stage_stride : 0u);
+        uint32_t symb = a.sym_off;                                            // where phase 2 finds the tile's symbols
         // ---------------- phase 1: input -> stream-ordered symbols in LDS ----------------
-        if constexpr (!IL) {
+        if (fast) {
             barrier_input(younger);                                           // this tile's input has landed, everyone left phase 2
             T3_STAMP(0);
             uint32_t ticket = 0;
             if (dyn && tid == 0) ticket = atomicAdd(ctr, 1u);                 // drawn three tiles ahead: its latency hides under a whole tile
 #ifndef T3_ABL_NO_PREFETCH
             if (nxt < a.n_tiles && wave >= w0)
-                stage_input<FE>(a, a.stage_off + (par ^ 1u) * a.stage_stride, first_group(nxt * TS), (nxt * TS + TS + GS - 1u) / GS, lane, wave - w0, nwv - w0);
+                stage_input<FE>(a, a.stage_off + (par ^ 1u) * a.stage_stride, first_group(need_lo(nxt * TS)), (need_hi(nxt * TS) + GS - 1u) / GS, lane, wave - w0, nwv - w0);
 #endif
             T3_STAMP(4);
 #ifndef T3_ABL_NO_P1
-            if constexpr (FE == FE_PIXELS) convert_pixels_packed<(1 << SH)>(a, stage, ((uint64_t)first_group(S0) * kGroupBytes) & ~15ull, S0, TS, lane, wave, nwv);
+            const uint32_t u_lo = need_lo(S0), u_hi = need_hi(S0);
+            if constexpr (FE == FE_PIXELS) convert_pixels_packed<(1 << SH)>(a, stage, ((uint64_t)first_group(u_lo) * kGroupBytes) & ~15ull, u_lo, u_hi, lane, wave, nwv);
             else convert_groups<FE, false, SH>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, tid, nthr);
 #endif
             T3_STAMP(5);                                                      // (diagnostic) this wave's conversion
@@ -755,6 +769,24 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             barrier_lds();                                                    // symbols complete
             T3_STAMP(1);
             nn = dyn ? __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + 328)) : nxt + gridDim.x;   // the tile after the next one
+            if constexpr (IL) {
+                // permutation pass: post-interleave position v of the tile <- pre-interleave symbol il_perm(v) (an involution);
+                // one lane = 4 consecutive positions = one dword of the image phase 2 reads
+                for (uint32_t g = tid; 4u * g < TS; g += nthr) {
+                    uint32_t v = S0 + 4u * g, w4 = 0;
+                    IlCursor cur;
+                    if (v < a.n_sym) cur.init(v, a);
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q, ++v) {
+                        uint32_t u = v;
+                        if (v < a.n_sym) { u = cur.get(); cur.next(a); }
+                        w4 |= lds_u8(a.sym_off + (u - u_lo)) << (8u * q);
+                    }
+                    *T3_LDS_WPTR(uint32_t, stage + 4u * g) = w4;
+                }
+                barrier_lds();
+                symb = stage;
+            }
         } else {
             nn = nxt + gridDim.x;
             __syncthreads();                                                  // everyone left phase 2 of the previous tile
@@ -782,17 +814,17 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             const uint32_t item = tid;                                        // one lane = one block, dealt linearly across the bands
             bool did = false;
             if constexpr (RSEL != 0) {
-                younger = phase2_mfma<RSEL>(a, tile, wave, lane, Afr);
+                younger = phase2_mfma<RSEL>(a, symb, tile, wave, lane, Afr);
             } else if (item < a.n_items) {
                 uint32_t b = 0;
 #pragma unroll
                 for (uint32_t q = 1; q < 9; ++q) if (item >= band_first(q)) b = q;
                 const uint32_t m = item - band_first(b), nbt = band_row(b).nbt;
                 switch (band_row(b).k) {                                         // lanes of one wave may sit in two bands (mixed k: divergent)
-                    case 24: did = phase2_band<2, false>(a, tile, b, m, nbt); break;
-                    case 22: did = phase2_band<4, false>(a, tile, b, m, nbt); break;
-                    case 20: did = phase2_band<6, false>(a, tile, b, m, nbt); break;
-                    default: did = phase2_band<8, false>(a, tile, b, m, nbt); break;
+                    case 24: did = phase2_band<2, false>(a, symb, tile, b, m, nbt); break;
+                    case 22: did = phase2_band<4, false>(a, symb, tile, b, m, nbt); break;
+                    case 20: did = phase2_band<6, false>(a, symb, tile, b, m, nbt); break;
+                    default: did = phase2_band<8, false>(a, symb, tile, b, m, nbt); break;
                 }
             }
             // single-k kernels count the store instructions issued after the prefetch (see phase2_mfma); the mixed kernel
