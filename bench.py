@@ -203,7 +203,7 @@ def main():
                                   "bound": "hbm", "achieved": round(dec_bytes / (dec_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(dec_bytes / (dec_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                                   "algorithmic_bytes_per_launch": dec_bytes, "launch_ms": round(dec_avg, 4)}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:        # reported baseline, timed on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(orc, ol, px)
     print(json.dumps(out))
     if world > 1:
