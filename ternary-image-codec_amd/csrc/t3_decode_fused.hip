@@ -57,30 +57,30 @@ template <int R>
 __device__ __forceinline__ bool fx_correct(const uint32_t* S, Fix& fx, const uint32_t* __restrict__ root_tbl, uint32_t FMA) {
     auto fma = [FMA](uint32_t acc, uint32_t x, uint32_t y) -> uint32_t { return l8(FMA + (x * 27u + y) * 27u + acc); };   // acc + x y
     constexpr int T = R / 2, NP = R + 2;
-    uint32_t sg[NP], bx[NP];                                        // sigma, and x^m * B (B shifted as the reference's xmdB)
+    // sigma, and x^m * B as the reference's xmdB.  B = (sigma before the last length change) / (its discrepancy): the division is
+    // kept as the scalar `binv` and applied to the discrepancy instead (d binv) * x^m * sigma_old -- one product per
+    // iteration instead of one per coefficient, the same field elements in the end
+    uint32_t sg[NP], bx[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) { sg[i] = 0; bx[i] = 0; }
     sg[0] = 1; bx[1] = 1;
-    uint32_t L = 0;
+    uint32_t L = 0, binv = 1;
 #pragma unroll
     for (int n = 0; n < R; ++n) {
         uint32_t d = S[n];
 #pragma unroll
         for (int i = 1; i <= n; ++i) d = fma(d, sg[i], S[n - i]);           // sigma[i] = 0 beyond L: same sum as OLD:572
         const bool upd = d != 0 && 2u * L <= (uint32_t)n;
-        const uint32_t iv = l8(INV + d), nd = l8(NEG + d);
-        uint32_t nb[NP];
+        const uint32_t nc = l8(NEG + gfm(d, binv));                          // -(d / d_old)
+        uint32_t old[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            if (i <= n + 1) {
-                const uint32_t old = sg[i];
-                sg[i] = fma(old, nd, bx[i]);                                 // old - d bx; d == 0: unchanged (OLD:573-587)
-                nb[i] = gfm(old, iv);                                        // T * inv(delta) (OLD:590-592)
-            } else nb[i] = 0;
+            old[i] = sg[i];
+            if (i <= n + 1) sg[i] = fma(old[i], nc, bx[i]);                  // sigma - d B x^m; d == 0: unchanged (OLD:573-587)
         }
-        if (upd) L = (uint32_t)n + 1u - L;
+        if (upd) { L = (uint32_t)n + 1u - L; binv = l8(INV + d); }           // B <- T / delta (OLD:590-592)
 #pragma unroll
-        for (int i = NP - 1; i >= 1; --i) bx[i] = upd ? nb[i - 1] : bx[i - 1];   // next x^m * B
+        for (int i = NP - 1; i >= 1; --i) bx[i] = upd ? old[i - 1] : bx[i - 1];  // next x^m * B (unscaled)
         bx[0] = 0;
     }
     uint32_t deg = 0;
