@@ -201,7 +201,11 @@ __global__ __launch_bounds__(512, 4) void decode_fixed_kernel(const DecFxArgs a)
                 }
                 uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0;
 #pragma unroll
+#ifdef T3_ABL_DEC_NO_SYND
+                for (uint32_t i = 0; i < 0; ++i) {
+#else
                 for (uint32_t i = 0; i < 26; ++i) {
+#endif
                     const u32x2 A = *T3_LP(const u32x2, kFxLut + i * SLAB + d8[i]);
                     const u32x2 B = *T3_LP(const u32x2, kFxLut + i * SLAB + 256u + d8[i]);
                     acc0 += A.x; acc1 += A.y; acc2 += B.x; acc3 += B.y;
