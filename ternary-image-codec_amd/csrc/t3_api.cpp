@@ -88,6 +88,26 @@ int get_mfma_lut(int k, int mode, const LutImage** out) {
     return T3_OK;
 }
 
+// tables of the UEP matrix-core kernel: the k-independent T/M image, then the A operand of every k in use (k_off = its offset)
+int get_mfma_group_lut(uint32_t kmask, int mode, const LutImage** out) {
+    const uint32_t key = kmask | (uint32_t)mode << 8 | 2u << 16;
+    auto it = g.luts.find(key);
+    if (it == g.luts.end()) {
+        LutImage L; std::vector<uint32_t> all;
+        for (int i = 0; i < 4; ++i) if (kmask >> i & 1) {
+            std::vector<uint32_t> afrag, img; build_mfma_encode(kOfIndex[i], mode, afrag, img);
+            if (all.empty()) all = img;                                   // T and M tables do not depend on k
+            L.k_off[i] = (uint32_t)all.size() * 4u;
+            all.insert(all.end(), afrag.begin(), afrag.end());
+        }
+        L.bytes = (uint32_t)all.size() * 4u;
+        HIPCHK(hipMalloc((void**)&L.d_img, L.bytes)); HIPCHK(hipMemcpy(L.d_img, all.data(), L.bytes, hipMemcpyHostToDevice));
+        it = g.luts.emplace(key, L).first;
+    }
+    *out = &it->second;
+    return T3_OK;
+}
+
 DevDiv to_dev(FastDiv f) { return DevDiv{f.mul, f.sh, f.d}; }
 uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
 uint64_t gcd64(uint64_t a, uint64_t b) { while (b) { uint64_t t = a % b; a = b; b = t; } return a; }
@@ -109,7 +129,9 @@ uint32_t p1_waves_per_parity(uint32_t TS) {
     return (worst + 63) / 64;
 }
 
-bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, int fe, const LutImage& lut, EncLaunch& out) {
+// grp = true: UEP on the matrix cores (all nine bands, several k): bands are grouped by k, a group's blocks of a tile are
+// dealt linearly into sets of 32; eight waves take two sets each
+bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, int fe, const LutImage& lut, EncLaunch& out, bool grp = false) {
     EncArgs& a = out.a; memset(&a, 0, sizeof a);
     const uint32_t GS = fe == FE_PIXELS ? kGroupSyms : kGroupSymsW, GB = fe == FE_PIXELS ? kGroupBytes : kGroupBytesW;
     uint64_t Lk = 2;
@@ -118,6 +140,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     // 2-D through the pipelined flow: a tile's input then covers the row segments it overlaps (up to w - 1 extra symbols each side)
     const bool il_async = L.interleave2d && fe == FE_PIXELS && cfg.tile_w <= 512;
     const uint32_t il_extra = il_async ? 2u * cfg.tile_w : 0u;
+    const uint32_t hdr = grp ? (uint32_t)kLdsHdrUep : (uint32_t)kLdsHdr;
     bool mixed = false;
     { int k0 = 0; for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) { if (!k0) k0 = L.band_k[b]; else if (k0 != L.band_k[b]) mixed = true; } }
     // pick q: tile = 9*Lk*q stream symbols; band b then owns Lk*q/k_b blocks
@@ -125,7 +148,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     for (int pass = 0; pass < 2 && !best_q; ++pass) {
         const uint32_t budget = pass == 0 ? 53u * 1024u : 160u * 1024u;     // <= 53 KiB: three workgroups per CU
         for (uint32_t q = 1; q <= 4096; ++q) {
-            if (mixed && (q & 1u)) continue;                             // mixed k: even multipliers only (measured: odd ones halve the LUT kernel's speed)
+            if (mixed && !grp && (q & 1u)) continue;                     // mixed k, LUT kernel: even multipliers only (measured: odd ones halve its speed)
             const uint64_t Lq = Lk * q; if (9 * Lq > 60000) break;
             uint32_t waves = 0, blocks_total = 0;
             for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) {
@@ -133,14 +156,23 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
                 blocks_total += nb;
             }
             waves = (blocks_total + 63) / 64;                          // lanes are dealt to blocks linearly across bands
+            uint32_t sets = 0;
+            if (grp) {
+                for (int i = 0; i < 4; ++i) { uint32_t items = 0; for (int b = 0; b < 9; ++b) if (k_index(L.band_k[b]) == i) items += (uint32_t)(Lq / L.band_k[b]); sets += (items + 31) / 32; }
+                if (sets > (uint32_t)kMaxSets || pass > 0) break;
+                waves = 8;
+            }
             if (waves > (pass == 0 ? 8u : (uint32_t)kMaxWaves)) break;   // pass 0: 512-thread workgroups, three per CU
             const uint32_t groups = (uint32_t)((9 * Lq + il_extra) / GS) + 8, stage = groups * GB + 1024 + 32;   // +1 KiB: LDS-DMA pieces are whole
-            const uint32_t total = kLdsHdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq) + il_extra) + kSymBack + ((L.interleave2d && !il_async) ? 1u : 2u) * round16(stage);
+            const uint32_t total = hdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq) + il_extra) + kSymBack + ((L.interleave2d && !il_async) ? 1u : 2u) * round16(stage);
             if (total > budget) break;
             // wave-instructions per stream symbol: phase 2 costs ~180 per wave, phase 1 (pixels) ~120 per wave-iteration
             const uint32_t wpp = p1_waves_per_parity((uint32_t)(9 * Lq) + il_extra);
             if (fe == FE_PIXELS && wpp > std::max(waves, 4u)) continue;
-            const double cost = (180.0 * waves + (fe == FE_PIXELS ? 220.0 * wpp : 180.0 * waves)) / (double)(9 * Lq);
+            // UEP kernel: the phases are barrier-separated and a wave runs its sets one after the other, so a tile costs one
+            // phase-1 pass plus ceil(sets / 8) set times, whatever the number of busy waves
+            const double cost = grp ? (220.0 + 100.0 * ((sets + 7) / 8)) / (double)(9 * Lq)
+                                    : (180.0 * waves + (fe == FE_PIXELS ? 220.0 * wpp : 180.0 * waves)) / (double)(9 * Lq);
             const double score = 1.0 / cost + 1e-9 * (double)Lq;
             if (score > best_score) { best_score = score; best_q = q; }
         }
@@ -148,7 +180,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     if (!best_q) return false;
     const uint32_t Lq = (uint32_t)(Lk * best_q);
     a.Lq = Lq; a.lut_bytes = round16(lut_bytes);
-    uint32_t off = kLdsHdr + a.lut_bytes;
+    uint32_t off = hdr + a.lut_bytes;
     off += kSymFront; a.sym_off = off; off += round16(9 * Lq + il_extra) + kSymBack;   // slack either side: phase 1 writes whole pixel triples
     a.stage_off = off;
     a.stage_groups = (9 * Lq + il_extra) / GS + 8;
@@ -156,7 +188,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     for (int b = 0; b < 9; ++b) {
         a.band_k[b] = L.band_k[b]; a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b];
         a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6);
-        a.band_lut_off[b] = kLdsHdr + lut.k_off[k_index(L.band_k[b])];
+        a.band_lut_off[b] = hdr + lut.k_off[k_index(L.band_k[b])];
         if (!(band_mask >> b & 1)) { a.band_nb_tile[b] = 0; a.band_blocks[b] = 0; continue; }
         const uint32_t nb = Lq / L.band_k[b];
         a.band_nb_tile[b] = nb;
@@ -183,6 +215,22 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     out.rsel = 0;
     { int k0 = 0; bool same = true; for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) { if (!k0) k0 = L.band_k[b]; else if (k0 != L.band_k[b]) same = false; } if (same && k0 && band_mask == 0x1FF) out.rsel = 26 - k0; }
     a.nb_uniform = out.rsel ? a.band_nb_tile[0] : 0u; a.div_nb = to_dev(fastdiv(a.nb_uniform ? a.nb_uniform : 1u));
+    if (grp) {
+        out.rsel = 1; out.block = 512;
+        uint32_t ng = 0, ns = 0;
+        for (int i = 0; i < 4; ++i) {
+            EncArgs::Grp& G = a.grp[ng]; memset(&G, 0, sizeof G);
+            uint32_t nbands = 0;
+            for (int b = 0; b < 9; ++b) if (k_index(L.band_k[b]) == i) G.bands[nbands++] = (uint8_t)b;
+            if (!nbands) continue;
+            G.nb = Lq / (uint32_t)kOfIndex[i]; G.div_nb = to_dev(fastdiv(G.nb)); G.n_items = nbands * G.nb; G.r = 26u - (uint32_t)kOfIndex[i];
+            G.afrag_off = hdr + lut.k_off[i];
+            mfma_scrambler_table(kOfIndex[i], sc, G.scr);
+            for (uint32_t it0 = 0; it0 < G.n_items; it0 += 32) a.set_tab[ns++] = ng | it0 << 8;
+            ++ng;
+        }
+        a.n_grp = ng; a.n_sets = ns;
+    }
     return true;
 }
 
@@ -247,7 +295,8 @@ int launch_fn(const void* fn, const EncLaunch& e, hipStream_t s) {
 }
 template <int FE, bool IL> int launch_enc2(const EncLaunch& e, hipStream_t s) {
     const void* fn = (const void*)encode_kernel_mixed<FE, IL>;
-    if (e.a.afrag) switch (e.rsel) {                           // single-k launches: matrix-core kernels (<= 640 threads)
+    if (e.rsel == 1) fn = (const void*)encode_kernel_uep<FE, IL>;   // UEP on the matrix cores
+    else if (e.a.afrag) switch (e.rsel) {                      // single-k launches: matrix-core kernels (<= 640 threads)
         case 2: fn = (const void*)encode_kernel_k<FE, IL, 2>; break;
         case 4: fn = (const void*)encode_kernel_k<FE, IL, 4>; break;
         case 6: fn = (const void*)encode_kernel_k<FE, IL, 6>; break;
@@ -295,11 +344,16 @@ int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, vo
         uint32_t km = 0; for (int b = 0; b < 9; ++b) if (m >> b & 1) km |= 1u << k_index(L.band_k[b]);
         bool mfma = single_k && m == 0x1FF;
         const LutImage* lut; EncLaunch e;
+        bool uep = false;
+        if (!single_k && m == 0x1FF) {                                   // several k, one launch: try the matrix-core UEP kernel
+            rc = get_mfma_group_lut(kmask, cfg->mode, &lut); if (rc) return rc;
+            uep = plan_enc_group(L, *cfg, m, fe, *lut, e, true);
+        }
         if (mfma) {                                                      // matrix-core kernel: 64 or 32 blocks per band and tile
             rc = get_mfma_lut(L.band_k[0], cfg->mode, &lut); if (rc) return rc;
             mfma = plan_enc_group(L, *cfg, m, fe, *lut, e) && e.rsel && e.block <= 512;   // the tile must fit eight waves
         }
-        if (!mfma) {
+        if (!mfma && !uep) {
             rc = get_lut(km, cfg->mode, &lut); if (rc) return rc;
             if (!plan_enc_group(L, *cfg, m, fe, *lut, e)) return T3_E_ARG;
         }

@@ -8,7 +8,10 @@ namespace t3 {
 enum FrontEnd : int { FE_PIXELS = 0, FE_WORDS = 1 };
 
 constexpr int kMaxWaves = 16;            // 1024-thread workgroup
-constexpr int kLdsHdr = 512;            // LDS header: 9 band rows (32 B) + wave roles
+constexpr int kLdsHdr = 512;            // LDS header: 9 band rows (32 B), item prefix, ticket slot, scrambler dwords
+constexpr int kLdsHdrUep = 1024;        // ... of the UEP matrix-core kernel: + group records and the set table
+constexpr int kHdrGrp = 384, kHdrGrpStride = 96, kHdrSets = 768;   // header offsets of the group records and the set table (UEP matrix-core kernel)
+constexpr int kMaxGrp = 4, kMaxSets = 16;
 constexpr int kSymFront = 64;           // slack in front of the LDS symbol buffer (phase 1 writes whole pixel triples) ...
 constexpr int kSymBack = 64;            // ... and behind it
 constexpr int kGroupSyms = 26;           // symbols one phase-1 lane produces from pixels: 6 px = 36 B -> 26 symbols
@@ -46,6 +49,10 @@ struct EncArgs {
     uint32_t  stage_groups;         // capacity of one input stage buffer, in lane groups
     uint32_t  cyc24; uint32_t pre0, pre1;      // scrambler: 6-periodic tail as 2-bit fields (x2), two pre-period states
     uint32_t  scr[12];              // single-k launches: scrambler dwords of the parity symbols per phase (mfma_scrambler_table)
+    // UEP on the matrix cores: bands grouped by k; a group's blocks of a tile are dealt linearly into sets of 32
+    struct Grp { uint32_t nb; DevDiv div_nb; uint32_t n_items, r; uint8_t bands[12]; uint32_t afrag_off; uint32_t scr[12]; } grp[kMaxGrp];   // afrag_off: LDS offset of the group's A operand
+    uint32_t  n_grp, n_sets;
+    uint32_t  set_tab[kMaxSets];    // group | first item << 8
     uint32_t  il_on, il_w, il_A;    // 2-D boustrophedon: row width, chunk area (clamped to n_sym)
     uint32_t  il_async;             // 2-D through the pipelined flow (pixels, moderate row width): symbol and stage buffers sized for the rows a tile overlaps
     DevDiv    div_A, div_w;

@@ -319,21 +319,28 @@ struct __attribute__((packed, aligned(2))) U32a2 { uint32_t v; };
 struct __attribute__((packed, aligned(2))) U128a2 { uint32_t v[4]; };
 constexpr uint32_t kMfmaModOff = 3 * 4096, kMfmaScr = 336;     // must match t3_host.hpp; scrambler dwords sit in the LDS header
 
-template <int R>
-__device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t symb, uint32_t tile, uint32_t wave, uint32_t lane, const v4i (&Afr)[3]) {
+// How the (up to) two sets of a call map to blocks: set s covers items item0[s] .. item0[s] + 31 of a run of n_items blocks
+// dealt linearly over bands that share k: item -> (band index item / nb, block item % nb); band_tab = LDS address of the
+// index -> band bytes (UEP groups) or ~0 for the identity (one k on all nine bands).
+struct P2Map { uint32_t item0[2]; uint32_t n_items, nb; DevDiv div_nb; uint32_t band_tab, scr_off; };
+
+template <int R, bool GRP>      // GRP: UEP group call (one set, band table, the group's scrambler dwords); else one k on all nine bands (two sets)
+__device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t symb, uint32_t tile, uint32_t lane, const v4i (&Afr)[3], const P2Map& M) {
     constexpr uint32_t K = 26 - R, H = R / 2;
-    constexpr uint32_t TB = kLdsHdr, MB = kLdsHdr + kMfmaModOff;
+    constexpr uint32_t TB = GRP ? kLdsHdrUep : kLdsHdr, MB = TB + kMfmaModOff;
     const uint32_t n = lane & 31u, h = lane >> 5;
-    const uint32_t tb3 = __builtin_amdgcn_readfirstlane((tile * a.nb_uniform) % 3u);
+    const uint32_t tb3 = __builtin_amdgcn_readfirstlane((tile * M.nb) % 3u);
     // A wave does two sets of 32 blocks.  The table reads of BOTH sets are issued before either set's MFMA chain, so the
     // second set's two dependent LDS round trips hide under the first set's chain and epilogue.
     struct Set { v4i Bv[3]; uint32_t W[3]; uint32_t c0, mg; uint64_t goff; bool valid, first; uint32_t dd0, dd1; };
     auto load = [&](uint32_t set, Set& s) {
-        const uint32_t item = wave * 64u + set * 32u + n;                     // blocks are dealt linearly across the bands
-        const uint32_t b = min(fdiv(item, a.div_nb), 8u), m = item - b * a.nb_uniform;
+        const uint32_t item = M.item0[set] + n;                               // blocks are dealt linearly across the bands (item0 huge: no set)
+        const uint32_t bi = min(fdiv(item, M.div_nb), 8u), m = item - bi * M.nb;
+        uint32_t b = bi;
+        if constexpr (GRP) b = lds_u8(M.band_tab + bi);
         const BandRow r = band_row(b);
-        s.mg = tile * a.nb_uniform + m;
-        s.valid = item < a.n_items && s.mg < r.blocks;                        // lanes without a block run along (reads stay inside LDS) and store nothing
+        s.mg = tile * M.nb + m;
+        s.valid = item < M.n_items && s.mg < r.blocks;                        // lanes without a block run along (reads stay inside LDS) and store nothing
         s.goff = r.body_off + 26ull * s.mg;
         s.first = r.body_off == 0 && s.mg == 0 && h == 0;
         // scrambler phase of the block's first symbol: (boff6 + 2 (mg mod 3)) mod 6 (26 == 2 mod 6), without wide multiplies
@@ -365,7 +372,7 @@ __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t symb,
     auto finish = [&](Set& s) -> uint32_t {
         uint32_t c0K = s.c0 + (K % 6u); c0K -= c0K >= 6u ? 6u : 0u;           // scrambler phase of the first parity symbol
         if constexpr (R >= 4) {     // the states of the parity symbols ride in unused positions of the upper half (see mfma_scr_pos)
-            const u32x2 sd = *T3_LDS_PTR(u32x2, kMfmaScr + 8u * c0K);
+            const u32x2 sd = *T3_LDS_PTR(u32x2, (GRP ? M.scr_off : (uint32_t)kMfmaScr) + 8u * c0K);
             if constexpr (R == 4) s.Bv[2][2] = h ? (int)sd.x : s.Bv[2][2];
             else { s.Bv[2][0] = h ? (int)sd.x : s.Bv[2][0]; s.Bv[2][1] = h ? (int)sd.y : s.Bv[2][1]; }
         }
@@ -422,8 +429,11 @@ __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t symb,
         return 0u;
 #endif
     };
-    Set s0, s1;
-    load(0, s0); load(1, s1);
+    Set s0;
+    load(0, s0);
+    if constexpr (GRP) return finish(s0);                                    // UEP path: one set per call
+    Set s1;
+    load(1, s1);
     uint32_t issued = finish(s0);
     issued += finish(s1);
     return issued;
@@ -688,9 +698,23 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
         for (int b = 0; b < 10; ++b) *(uint32_t*)(lds + 288 + 4 * b) = a.band_first[b];
 #pragma unroll
         for (int i = 0; i < 12; ++i) *(uint32_t*)(lds + 336 + 4 * i) = a.scr[i];
+        if constexpr (RSEL == 1) {                                            // UEP group records and the set table
+#pragma unroll
+            for (int gi = 0; gi < kMaxGrp; ++gi) {
+                uint32_t* gp = (uint32_t*)(lds + kHdrGrp + kHdrGrpStride * gi);
+                gp[0] = a.grp[gi].nb; gp[1] = a.grp[gi].div_nb.mul; gp[2] = a.grp[gi].div_nb.sh; gp[3] = a.grp[gi].div_nb.d;
+                gp[4] = a.grp[gi].n_items; gp[5] = a.grp[gi].r; gp[9] = a.grp[gi].afrag_off;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gp[6 + q] = (uint32_t)a.grp[gi].bands[4 * q] | (uint32_t)a.grp[gi].bands[4 * q + 1] << 8 | (uint32_t)a.grp[gi].bands[4 * q + 2] << 16 | (uint32_t)a.grp[gi].bands[4 * q + 3] << 24;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) gp[12 + q] = a.grp[gi].scr[q];
+            }
+#pragma unroll
+            for (int q = 0; q < kMaxSets; ++q) *(uint32_t*)(lds + kHdrSets + 4 * q) = a.set_tab[q];
+        }
     }
     for (uint32_t i = tid * 16u; i < a.lut_bytes; i += nthr * 16u)
-        *(uint4*)(lds + kLdsHdr + i) = *(const uint4*)((const uint8_t*)a.lut_img + i);
+        *(uint4*)(lds + (RSEL == 1 ? kLdsHdrUep : kLdsHdr) + i) = *(const uint4*)((const uint8_t*)a.lut_img + i);
 
     if (blockIdx.x == 0 && a.frame_out) {                                    // header symbols + zero tail (OLD:1159-1167)
         if (tid == 0) {                                                      // constant indices only (see above)
@@ -701,7 +725,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     }
 
     v4i Afr[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};                   // single-k kernels: the parity matrix lives in 12 VGPRs
-    if constexpr (RSEL != 0) {
+    if constexpr (RSEL > 1) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) Afr[s] = ((const v4i*)a.afrag)[s * 64 + lane];
     }
@@ -813,8 +837,34 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
         {
             const uint32_t item = tid;                                        // one lane = one block, dealt linearly across the bands
             bool did = false;
-            if constexpr (RSEL != 0) {
-                younger = phase2_mfma<RSEL>(a, symb, tile, wave, lane, Afr);
+            if constexpr (RSEL > 1) {                                          // one k on all nine bands: both sets of the wave in one call
+                P2Map M; M.item0[0] = wave * 64u; M.item0[1] = wave * 64u + 32u; M.n_items = a.n_items; M.nb = a.nb_uniform; M.div_nb = a.div_nb;
+                M.band_tab = ~0u; M.scr_off = kMfmaScr;
+                younger = phase2_mfma<RSEL, false>(a, symb, tile, lane, Afr, M);
+            } else if constexpr (RSEL == 1) {                                  // UEP: a set lies inside one group of bands that share k
+                younger = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 2; ++q) {
+                    const uint32_t set = wave + 8u * q;                         // sets go round the eight waves
+                    if (set >= a.n_sets) continue;
+                    const uint32_t st = __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + kHdrSets + 4u * set));
+                    const uint32_t gb = kHdrGrp + kHdrGrpStride * (st & 0xFFu);
+                    P2Map M; M.item0[0] = st >> 8; M.item0[1] = 0xFFFF0000u;
+                    M.nb = __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + gb)); M.div_nb.mul = __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + gb + 4));
+                    M.div_nb.sh = __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + gb + 8)); M.div_nb.d = __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + gb + 12));
+                    M.n_items = __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + gb + 16));
+                    const uint32_t rr = __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + gb + 20)), ao = __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + gb + 36));
+                    M.band_tab = gb + 24u; M.scr_off = gb + 48u;
+                    v4i Ag[3];
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) Ag[s] = *T3_LDS_PTR(v4i, ao + 16u * (s * 64u + lane));
+                    switch (rr) {
+                        case 2: younger += phase2_mfma<2, true>(a, symb, tile, lane, Ag, M); break;
+                        case 4: younger += phase2_mfma<4, true>(a, symb, tile, lane, Ag, M); break;
+                        case 6: younger += phase2_mfma<6, true>(a, symb, tile, lane, Ag, M); break;
+                        default: younger += phase2_mfma<8, true>(a, symb, tile, lane, Ag, M); break;
+                    }
+                }
             } else if (item < a.n_items) {
                 uint32_t b = 0;
 #pragma unroll
@@ -856,12 +906,14 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 template <int FE, bool IL, int RSEL>
 __global__ __launch_bounds__(512, T3_ENC_WAVES_PER_EU) void encode_kernel_k(const EncArgs a) { encode_body<FE, IL, RSEL>(a); }
 template <int FE, bool IL>
+__global__ __launch_bounds__(512, T3_ENC_WAVES_PER_EU) void encode_kernel_uep(const EncArgs a) { encode_body<FE, IL, 1>(a); }   // UEP on the matrix cores
+template <int FE, bool IL>
 __global__ __launch_bounds__(1024) void encode_kernel_mixed(const EncArgs a) { encode_body<FE, IL, 0>(a); }
 
 #define T3_INST_K(FE, IL) \
     template __global__ void encode_kernel_k<FE, IL, 2>(const EncArgs); template __global__ void encode_kernel_k<FE, IL, 4>(const EncArgs); \
     template __global__ void encode_kernel_k<FE, IL, 6>(const EncArgs); template __global__ void encode_kernel_k<FE, IL, 8>(const EncArgs); \
-    template __global__ void encode_kernel_mixed<FE, IL>(const EncArgs);
+    template __global__ void encode_kernel_mixed<FE, IL>(const EncArgs); template __global__ void encode_kernel_uep<FE, IL>(const EncArgs);
 T3_INST_K(FE_PIXELS, false) T3_INST_K(FE_PIXELS, true) T3_INST_K(FE_WORDS, false) T3_INST_K(FE_WORDS, true)
 
 // ---------------------------------------------------------------------------------------------------------
