@@ -198,6 +198,11 @@ int t3hip_frame_record_dev(const void* d_words9, uint64_t n_words, uint64_t fram
                            const t3_cfg* cfg, t3_frame_record* d_rec, void* d_scratch,
                            uint64_t scratch_bytes, void* stream);
 uint64_t t3hip_frame_record_scratch_bytes(uint64_t n_words);
+/* Payload CRC of the T3P6/T3V6 containers (crc32_acc, src/io_t3p_t3v.cpp:20-36: poly 0xEDB88320, init and final
+ * inversion 0xFFFFFFFF) of a device buffer / a host buffer (uploaded, same kernel).  Synchronous: *crc_out is host
+ * memory and valid on return.  n_bytes == 0 gives 0, which is also what the containers store for an empty payload. */
+int t3hip_crc32_dev(const void* d_data, uint64_t n_bytes, uint32_t* crc_out, void* stream);
+int t3hip_crc32(const void* data, uint64_t n_bytes, uint32_t* crc_out);
 /* Host: sort gathered records by frame_idx and fill byte_offset (T3V index, io_t3p_t3v.cpp:252-289). */
 int t3hip_index_assemble(t3_frame_record* recs, uint64_t n_recs, uint64_t first_payload_offset);
 

@@ -1,0 +1,38 @@
+"""Launch times of the decode entry point (t3hip_decode_profile_dev, to pixels) for the FIXED-mode configurations, 8K frame,
+HIP events, 5 launches each; streams come from the encoder, clean or with 0..3 injected symbol errors per block."""
+import json, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as g
+import oracle_lib as ol
+import numpy as np
+t3 = g.load_package(); t3.init(0)
+W, H = 7680, 4320; NPX = W * H
+px = ol.oracle().lcg_pixels(NPX, 12345)
+d_px = torch.from_numpy(px.view(np.uint8)).cuda()
+s = torch.cuda.current_stream().cuda_stream
+def run(name, cfg):
+    n_raw = NPX // 2
+    n_enc = t3.encoded_words(n_raw, cfg)
+    coded = torch.zeros(n_enc * 9 + 64, dtype=torch.uint8, device="cuda")
+    t3.encode_frame_dev(d_px.data_ptr(), NPX, cfg, coded.data_ptr(), n_enc, s)
+    out = torch.zeros(NPX * 6 + 64, dtype=torch.uint8, device="cuda")
+    seen = t3.default_cfg(); seen.mode = cfg.mode
+    f = lambda: t3.decode_profile_dev(coded.data_ptr(), n_enc, seen, out.data_ptr(), NPX, True, s)
+    for _ in range(2): f()
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(out[:NPX * 6], d_px[:NPX * 6]))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): f()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    return {"config": name, "ms": round(ms, 4), "pixels_exact": ok, "GBps": round((6 * NPX + 9 * n_enc) / ms / 1e6, 1)}
+P = t3.ProfileID; F = t3.MODE_FIXED
+res = []
+res.append(run("C2 FIXED RS(26,20) 1-D (fused decoder), clean stream", t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=F)))
+res.append(run("FIXED luma-priority UEP 1-D (generic decoder), clean", t3.make_cfg(profile=P.P3_RS26_20, uep="luma", mode=F)))
+res.append(run("FIXED 2-D 64x64 RS(26,20) (generic decoder), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(64, 64), mode=F)))
+res.append(run("C3 FIXED 2-D 64x64 + luma UEP (generic decoder), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F)))
+res.append(run("C2 FIXED + beacon every 64 words (generic decoder), clean", t3.make_cfg(profile=P.P3_RS26_20, uep=2, beacon=(64, 4, 1), mode=F)))
+print(json.dumps(res, indent=1))

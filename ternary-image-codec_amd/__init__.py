@@ -466,6 +466,20 @@ def frame_record_dev(d_words, n_words, frame_idx, cfg, d_rec, d_scratch, scratch
     _chk(lib().t3hip_frame_record_dev(C.c_void_p(d_words), C.c_uint64(n_words), C.c_uint64(frame_idx), C.byref(cfg), C.c_void_p(d_rec), C.c_void_p(d_scratch), C.c_uint64(scratch_bytes), C.c_void_p(stream)), "t3hip_frame_record_dev")
 
 
+def crc32_dev(d_data, n_bytes, stream=0):
+    """CRC-32 of a device buffer (the containers' payload CRC, io_t3p_t3v.cpp:20-36), computed by crc_chunks_kernel."""
+    out = C.c_uint32()
+    _chk(lib().t3hip_crc32_dev(C.c_void_p(d_data), C.c_uint64(n_bytes), C.byref(out), C.c_void_p(stream)), "t3hip_crc32_dev")
+    return out.value
+
+
+def crc32(data):
+    """CRC-32 of host bytes: uploaded, then the same kernel (no CPU path)."""
+    buf = _u8(data); out = C.c_uint32()
+    _chk(lib().t3hip_crc32(_vp(buf), C.c_uint64(buf.size), C.byref(out)), "t3hip_crc32")
+    return out.value
+
+
 def index_assemble(records_bytes, first_payload_offset=0):
     """records_bytes: uint8 array of concatenated t3_frame_record; returns a list of FrameRecord sorted by frame_idx with offsets."""
     buf = np.ascontiguousarray(records_bytes, np.uint8).copy()

@@ -299,6 +299,49 @@ int t3hip_frame_record_dev(const void* d_words, uint64_t n_words, uint64_t frame
     HIPCHK(hipGetLastError()); return T3_OK;
 }
 
+int t3hip_crc32_dev(const void* d_data, uint64_t n_bytes, uint32_t* crc_out, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!crc_out || (n_bytes && !d_data)) return T3_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::recursive_mutex> lk(g_mail_mu);                       // one scratch accumulator per process
+    void* d_sc = d_crc_acc;
+    CrcArgs c; memset(&c, 0, sizeof c);
+    c.data = (const uint8_t*)d_data; c.n_bytes = n_bytes; c.chunk_bytes = 2304;
+    c.n_chunks = (uint32_t)((n_bytes + c.chunk_bytes - 1) / c.chunk_bytes);
+    c.chunk_crc = (uint32_t*)d_sc; c.sym_sum = (uint32_t*)d_sc + 1; c.zpow = d_zpow;
+    HIPCHK(hipMemsetAsync(d_sc, 0, 8, s));
+    if (c.n_chunks) { hipLaunchKernelGGL(crc_chunks_kernel, dim3((c.n_chunks + 255) / 256), dim3(256), 0, s, c); HIPCHK(hipGetLastError()); }
+    uint32_t acc = 0;
+    HIPCHK(hipMemcpyAsync(&acc, d_sc, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    // the kernel leaves the xor of the chunk remainders moved to the end of the stream; the leading 0xFFFFFFFF travels
+    // through n_bytes zero bytes on the host (bitwise, 8 n steps would be too slow: square-and-multiply on the operator)
+    uint32_t x = 0xFFFFFFFFu;
+    {
+        // operator "append 2^j zero bytes" as 32 columns; start with one zero byte
+        uint32_t op[32], sq[32];
+        for (int b = 0; b < 32; ++b) { uint32_t v = 1u << b; for (int i = 0; i < 8; ++i) v = (v & 1u) ? (0xEDB88320u ^ (v >> 1)) : (v >> 1); op[b] = v; }
+        auto apply = [](const uint32_t* m, uint32_t v) { uint32_t r = 0; for (int b = 0; b < 32; ++b) if (v >> b & 1u) r ^= m[b]; return r; };
+        for (uint64_t n = n_bytes; n; n >>= 1) {
+            if (n & 1u) x = apply(op, x);
+            for (int b = 0; b < 32; ++b) sq[b] = apply(op, op[b]);
+            memcpy(op, sq, sizeof op);
+        }
+    }
+    *crc_out = (x ^ acc) ^ 0xFFFFFFFFu;
+    return T3_OK;
+}
+
+int t3hip_crc32(const void* data, uint64_t n_bytes, uint32_t* crc_out) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!crc_out || (n_bytes && !data)) return T3_E_ARG;
+    std::lock_guard<std::recursive_mutex> lk(g_mail_mu);
+    void* di; int rc = api_scratch(0, n_bytes + 64, &di); if (rc) return rc;
+    hipStream_t s = api_stream();
+    if (n_bytes) HIPCHK(hipMemcpyAsync(di, data, n_bytes, hipMemcpyHostToDevice, s));
+    return t3hip_crc32_dev(di, n_bytes, crc_out, s);
+}
+
 int t3hip_index_assemble(t3_frame_record* recs, uint64_t n, uint64_t first_payload_offset) {
     if (n && !recs) return T3_E_ARG;
     std::sort(recs, recs + n, [](const t3_frame_record& x, const t3_frame_record& y) { return x.frame_idx < y.frame_idx; });

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "ternary_codec_v6.hpp"
+#include "io_t3p_t3v.hpp"
 
 static uint64_t fnv(const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } return h; }
 
@@ -35,7 +36,27 @@ int main(int argc, char** argv) {
     std::vector<UTrit> tr2; bool ok_b243 = tpack::base243_to_ut(b243, tr2) && tr2 == tr;
     std::vector<Word27> w24; build_words_from_subword_stream(tr2, 24, w24);
 
-    printf("{\"sub_trits\":%zu,\"sub_hash\":\"%016llx\",\"b243_bytes\":%zu,\"b243_hash\":\"%016llx\",\"ok_b243\":%d,\"w24_hash\":\"%016llx\",",
+    // row f2: the coded frame into a T3V6 / T3P6 container and back (io_t3p_t3v.hpp:40-84); payload CRC on the device
+    int cont_ok = 0; unsigned long long t3v_hash = 0; size_t t3v_bytes = 0;
+    if (argc > 3) {
+        const std::string dir = argv[3], v = dir + "/demo.t3v", pth = dir + "/demo.t3p";
+        std::string err;
+        bool okc = T3Container::t3v_write(v, SubwordMode::S27, w, h, {prof, {}, proff}, "{\"codec\":\"v6\"}", {"{\"f\":0}", "", "{\"f\":2}"}, &err);
+        SubwordMode sm; int rw = 0, rh = 0; std::string mg; uint64_t fc = 0; std::vector<T3Container::T3VFrameIndex> idx;
+        okc = okc && T3Container::t3v_read_header(v, sm, rw, rh, mg, fc, idx, &err) && fc == 3 && rw == w && rh == h && idx[0].words == prof.size() && idx[1].words == 0;
+        std::vector<Word27> back;
+        okc = okc && T3Container::t3v_read_frame(v, 2, nullptr, back, &err) && back.size() == proff.size() && memcmp(back.data(), proff.data(), 9 * back.size()) == 0;
+        okc = okc && T3Container::t3v_read_frame(v, 1, nullptr, back, &err) && back.empty();
+        okc = okc && !T3Container::t3v_read_frame(v, 0, [](const std::string& m) { return m != "{\"f\":0}"; }, back, &err) && back.empty();
+        okc = okc && T3Container::t3p_write(pth, SubwordMode::S24, w, h, raw, "{}", &err);
+        okc = okc && T3Container::t3p_read_payload(pth, nullptr, back, &err) && back.size() == raw.size() && memcmp(back.data(), raw.data(), 9 * raw.size()) == 0;
+        { FILE* f = fopen(pth.c_str(), "r+b"); fseek(f, 40, SEEK_SET); int c = fgetc(f); fseek(f, 40, SEEK_SET); fputc(c ^ 1, f); fclose(f); }   // flip a payload bit
+        okc = okc && !T3Container::t3p_read_payload(pth, nullptr, back, &err) && err == "t3p: payload crc mismatch";
+        cont_ok = okc ? 1 : 0;
+        if (FILE* f = fopen(v.c_str(), "rb")) { std::vector<uint8_t> all; uint8_t buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) all.insert(all.end(), buf, buf + n); fclose(f); t3v_bytes = all.size(); t3v_hash = fnv(all.data(), all.size()); }
+    }
+    printf("{\"containers_ok\":%d,\"t3v_bytes\":%zu,\"t3v_hash\":\"%016llx\",", cont_ok, t3v_bytes, t3v_hash);
+    printf("\"sub_trits\":%zu,\"sub_hash\":\"%016llx\",\"b243_bytes\":%zu,\"b243_hash\":\"%016llx\",\"ok_b243\":%d,\"w24_hash\":\"%016llx\",",
            tr.size(), (unsigned long long)fnv(tr.data(), tr.size()), b243.size(), (unsigned long long)fnv(b243.data(), b243.size()), ok_b243 ? 1 : 0,
            (unsigned long long)fnv(w24.data(), w24.size() * 9));
     printf("\"ok_raw\":%d,\"raw_words\":%zu,\"raw_hash\":\"%016llx\",\"ok_enc\":%d,\"enc_words\":%zu,\"enc_hash\":\"%016llx\",\"ok_dec_compat\":%d,"

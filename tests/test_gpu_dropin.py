@@ -33,7 +33,7 @@ def test_dropin_header_compiles_and_refuses_without_gpu(t3, tmp_path):
 @pytest.mark.gpu
 def test_dropin_caller_sequence(gpu, orc, tmp_path):
     exe = build_demo(str(tmp_path))
-    out = json.loads(subprocess.run([exe, "256", "256"], check=True, capture_output=True, text=True).stdout)
+    out = json.loads(subprocess.run([exe, "256", "256", str(tmp_path)], check=True, capture_output=True, text=True).stdout)
     px = orc.lcg_pixels(256 * 256)
     raw = orc.pack_pixels(px)
     cfg = ol.make_cfg(profile=1, uep=1, tile=(64, 64), beacon=(83, 2, 1))
@@ -51,3 +51,11 @@ def test_dropin_caller_sequence(gpu, orc, tmp_path):
     assert out["sub_trits"] == len(tr) and out["sub_hash"] == ol.fnv_hex(tr)
     assert out["b243_bytes"] == len(b243) and out["b243_hash"] == ol.fnv_hex(b243) and out["ok_b243"] == 1
     assert out["w24_hash"] == ol.fnv_hex(orc.build_words_from_subword_stream(tr, 24, 0))
+    # row f2: the containers written by the C++ header are byte-identical to the independent restatement in test_containers.py
+    assert out["containers_ok"] == 1
+    from test_containers import expect_t3v
+    cfgf = ol.make_cfg(profile=1, uep=1, tile=(64, 64), beacon=(83, 2, 1), mode=1)
+    rcf, encf = orc.encode_profile(raw, cfgf); assert rcf == 0
+    f0 = np.ascontiguousarray(enc).view(np.uint8).reshape(-1); f2 = np.ascontiguousarray(encf).view(np.uint8).reshape(-1)
+    want = expect_t3v(27, 256, 256, [f0, np.zeros(0, np.uint8), f2], b'{"codec":"v6"}', [b'{"f":0}', b"", b'{"f":2}'])
+    assert out["t3v_bytes"] == len(want) and out["t3v_hash"] == ol.fnv_hex(np.frombuffer(want, np.uint8))
