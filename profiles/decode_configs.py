@@ -1,5 +1,6 @@
 """Launch times of the decode entry point (t3hip_decode_profile_dev, to pixels) for the FIXED-mode configurations, 8K frame,
-HIP events, 5 launches each; streams come from the encoder, clean or with 0..3 injected symbol errors per block."""
+HIP events, 5 launches each (synchronous entry point: header read-back and verdict included); streams come from the
+encoder; the "errors" rows carry 0..t injected symbol errors in every block (t of the weakest band's code)."""
 import json, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,11 +12,14 @@ W, H = 7680, 4320; NPX = W * H
 px = ol.oracle().lcg_pixels(NPX, 12345)
 d_px = torch.from_numpy(px.view(np.uint8)).cuda()
 s = torch.cuda.current_stream().cuda_stream
-def run(name, cfg):
+def run(name, cfg, errors=False):
     n_raw = NPX // 2
     n_enc = t3.encoded_words(n_raw, cfg)
     coded = torch.zeros(n_enc * 9 + 64, dtype=torch.uint8, device="cuda")
     t3.encode_frame_dev(d_px.data_ptr(), NPX, cfg, coded.data_ptr(), n_enc, s)
+    if errors:
+        L = t3.plan(n_raw, cfg)
+        t3.inject_errors_dev(coded.data_ptr(), L.header_syms, L.body_syms // 26, 4242, (26 - max(L.band_k)) // 2, s)
     out = torch.zeros(NPX * 6 + 64, dtype=torch.uint8, device="cuda")
     seen = t3.default_cfg(); seen.mode = cfg.mode
     f = lambda: t3.decode_profile_dev(coded.data_ptr(), n_enc, seen, out.data_ptr(), NPX, True, s)
@@ -31,8 +35,10 @@ def run(name, cfg):
 P = t3.ProfileID; F = t3.MODE_FIXED
 res = []
 res.append(run("C2 FIXED RS(26,20) 1-D (fused decoder), clean stream", t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=F)))
-res.append(run("FIXED luma-priority UEP 1-D (generic decoder), clean", t3.make_cfg(profile=P.P3_RS26_20, uep="luma", mode=F)))
-res.append(run("FIXED 2-D 64x64 RS(26,20) (generic decoder), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(64, 64), mode=F)))
-res.append(run("C3 FIXED 2-D 64x64 + luma UEP (generic decoder), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F)))
-res.append(run("C2 FIXED + beacon every 64 words (generic decoder), clean", t3.make_cfg(profile=P.P3_RS26_20, uep=2, beacon=(64, 4, 1), mode=F)))
+res.append(run("FIXED luma-priority UEP 1-D (two-kernel decoder), clean", t3.make_cfg(profile=P.P3_RS26_20, uep="luma", mode=F)))
+res.append(run("FIXED 2-D 64x64 RS(26,20) (two-kernel decoder), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(64, 64), mode=F)))
+res.append(run("C3 FIXED 2-D 64x64 + luma UEP (two-kernel decoder), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F)))
+res.append(run("C2 FIXED + beacon every 64 words (strip pass + fused decoder), clean", t3.make_cfg(profile=P.P3_RS26_20, uep=2, beacon=(64, 4, 1), mode=F)))
+res.append(run("C2 FIXED RS(26,20) 1-D (fused decoder), 0..3 errors per block", t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=F), errors=True))
+res.append(run("C3 FIXED 2-D 64x64 + luma UEP (two-kernel decoder), 0..2 errors per block", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F), errors=True))
 print(json.dumps(res, indent=1))

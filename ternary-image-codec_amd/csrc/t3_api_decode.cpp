@@ -36,12 +36,9 @@ int k_index(int k) { return k == 24 ? 0 : k == 22 ? 1 : k == 20 ? 2 : k == 18 ? 
 std::mutex g_tab_mu;   // the lazily built device tables below are shared by every caller thread
 std::recursive_mutex g_mail_mu;   // ... and so are the pinned host mailboxes of the synchronous entry points
 
-int decode_fixed_fused(const void* d_in, uint64_t n_in, const t3_cfg& cfg, const t3_layout& L, const ScrCycle& sc,
-                       void* d_out, uint64_t units, int to_pixels, uint32_t* d_fail, hipStream_t s) {
-    if (L.beacon_on || L.interleave2d || L.n_raw_words == 0) return 1;
-    std::lock_guard<std::mutex> lk(g_tab_mu);
-    for (int b = 1; b < 9; ++b) if (L.band_k[b] != L.band_k[0]) return 1;
-    const int k = L.band_k[0], ki = k_index(k);
+// device tables of one code (syndrome LUT, root masks) and the multiply-accumulate table, built on first use
+int ensure_fx_tables(int k) {
+    const int ki = k_index(k);
     if (!d_synd_lut[ki]) {
         std::vector<uint32_t> img; build_syndrome_lut(k, img);
         synd_lut_bytes[ki] = (uint32_t)img.size() * 4u;
@@ -74,10 +71,21 @@ int decode_fixed_fused(const void* d_in, uint64_t n_in, const t3_cfg& cfg, const
         for (int x = 0; x < 27; ++x) for (int y = 0; y < 27; ++y) for (int c = 0; c < 27; ++c) t[(size_t)(x * 27 + y) * 27 + c] = F.t.add[c * 27 + F.t.mul[x * 27 + y]];
         HIPCHK(hipMalloc((void**)&d_fma, t.size())); HIPCHK(hipMemcpy(d_fma, t.data(), t.size(), hipMemcpyHostToDevice));
     }
+    return T3_OK;
+}
+
+// `body`: the coded stream with `hdr_syms` symbols of header in front of the band-serial body (the caller has stripped a beacon)
+int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_syms, const t3_layout& L, const ScrCycle& sc,
+                       void* d_out, uint64_t units, int to_pixels, uint32_t* d_fail, hipStream_t s) {
+    if (L.interleave2d || L.n_raw_words == 0) return 1;
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    for (int b = 1; b < 9; ++b) if (L.band_k[b] != L.band_k[0]) return 1;
+    const int k = L.band_k[0], ki = k_index(k);
+    { const int rc = ensure_fx_tables(k); if (rc) return rc; }
     DecFxArgs a; memset(&a, 0, sizeof a);
-    a.in = (const uint8_t*)d_in; a.in_bytes = 9 * n_in; a.out = d_out; a.n_units = units; a.fail = d_fail; a.roots = d_roots[ki];
+    a.in = body; a.in_bytes = body_bytes; a.out = d_out; a.n_units = units; a.fail = d_fail; a.roots = d_roots[ki];
     a.tab = d_fxtab; a.lut = d_synd_lut[ki]; a.lut_bytes = synd_lut_bytes[ki];
-    a.k = (uint32_t)k; a.nb = 52; a.TS = 9u * 52u * (uint32_t)k; a.n_sym = (uint32_t)L.n_sym; a.hdr_syms = L.header_syms;
+    a.k = (uint32_t)k; a.nb = 52; a.TS = 9u * 52u * (uint32_t)k; a.n_sym = (uint32_t)L.n_sym; a.hdr_syms = hdr_syms;
     uint64_t maxb = 0;
     for (int b = 0; b < 9; ++b) { a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b]; a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6); maxb = std::max<uint64_t>(maxb, L.band_blocks[b]); }
     a.n_tiles = (uint32_t)((maxb + a.nb - 1) / a.nb);
@@ -109,6 +117,92 @@ int decode_fixed_fused(const void* d_in, uint64_t n_in, const t3_cfg& cfg, const
 DevDiv to_dev(FastDiv f) { return DevDiv{f.mul, f.sh, f.d}; }
 unsigned grid_for(uint64_t items, unsigned block) { return (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, (items + block - 1) / block), 1u << 20); }
 
+int occupancy_of(const void* fn, int threads, uint32_t lds_bytes, int* out) {
+    static std::map<std::pair<const void*, uint32_t>, int> occ;
+    auto key = std::make_pair(fn, lds_bytes);
+    auto it = occ.find(key);
+    if (it == occ.end()) {
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int o = 1; HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, threads, lds_bytes));
+        it = occ.emplace(key, std::max(1, o)).first;
+    }
+    *out = it->second; return T3_OK;
+}
+
+// Two-kernel FIXED decode (t3_decode_stream.hip): any per-band k, 1-D or 2-D.  Returns T3_OK after launching, 1 if not applicable.
+int decode_fixed_stream(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_syms, const t3_cfg& cfg, const t3_layout& L, const ScrCycle& sc,
+                        void* d_out, uint64_t units, int to_pixels, uint32_t* d_fail, hipStream_t s) {
+    if (L.n_raw_words == 0 || L.n_sym + (1u << 20) >= (1ull << 32) || body_bytes + hdr_syms >= (1ull << 32)) return 1;
+    if (getenv("T3HIP_GENERIC_DECODE") != nullptr) return 1;
+    const bool il = L.interleave2d != 0;
+    if (il && cfg.tile_w > 4096) return 1;                                  // a span's rows are staged in LDS
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    DecStArgs a; memset(&a, 0, sizeof a);
+    // bands grouped by k, in order of first appearance
+    int gk[kStMaxGrp]; uint32_t gn[kStMaxGrp] = {0, 0, 0, 0}; int ng = 0;
+    for (int b = 0; b < 9; ++b) {
+        int g = -1;
+        for (int q = 0; q < ng; ++q) if (gk[q] == L.band_k[b]) g = q;
+        if (g < 0) { g = ng++; gk[g] = L.band_k[b]; }
+        a.grp[g].bands[gn[g]++] = (uint8_t)b;
+    }
+    uint32_t lcm = 1;
+    for (int g = 0; g < ng; ++g) { const int rc = ensure_fx_tables(gk[g]); if (rc) return rc; uint32_t x = lcm, y = (uint32_t)gk[g]; while (y) { const uint32_t t = x % y; x = y; y = t; } lcm = lcm / x * (uint32_t)gk[g]; }
+    // tile = 9 Lq stream symbols, Lq = lcm m: the m that fills the eight waves best with the tile's symbols within 16 KiB of LDS
+    uint32_t best_m = 0; double best = -1.0;
+    for (uint32_t m = 1; 9u * lcm * m <= 16384u; ++m) {
+        uint32_t slots = 0, items = 0;
+        for (int g = 0; g < ng; ++g) { const uint32_t n = gn[g] * (lcm * m / (uint32_t)gk[g]); items += n; slots += (n + 63u) / 64u; }
+        const double fill = (double)items / (512.0 * ((slots + 7u) / 8u));
+        if (fill > best + 1e-9) { best = fill; best_m = m; }
+    }
+    if (!best_m) best_m = 1;                                                // four different k: one lcm is already a large tile (LDS checked below)
+    const uint32_t Lq = lcm * best_m;
+    a.TS = 9u * Lq; a.n_sym = (uint32_t)L.n_sym; a.hdr_syms = hdr_syms; a.n_grp = (uint32_t)ng;
+    uint32_t off = kFxLut, slots = 0; uint64_t tiles = 0;
+    for (int g = 0; g < ng; ++g) {
+        const int ki = k_index(gk[g]);
+        auto& G = a.grp[g];
+        G.r = 26u - (uint32_t)gk[g]; G.nb = Lq / (uint32_t)gk[g]; G.n_items = gn[g] * G.nb; G.wave0 = slots; G.n_waves = (G.n_items + 63u) / 64u; slots += G.n_waves;
+        G.lut = d_synd_lut[ki]; G.lut_bytes = synd_lut_bytes[ki]; G.lut_off = off; off = (off + G.lut_bytes + 15u) & ~15u; G.roots = d_roots[ki];
+        for (uint32_t i = 0; i < gn[g]; ++i) tiles = std::max<uint64_t>(tiles, (L.band_blocks[G.bands[i]] + G.nb - 1) / G.nb);
+    }
+    a.n_slots = slots; a.n_tiles = (uint32_t)tiles;
+    a.fma = d_fma; a.fma_off = off; a.y_off = (off + 19696u + 15u) & ~15u; a.lds_bytes = a.y_off + a.TS + 64u;
+    if (a.lds_bytes > 150u * 1024u) return 1;
+    a.in = body; a.in_bytes = body_bytes; a.fail = d_fail; a.tab = d_fxtab;
+    for (int b = 0; b < 9; ++b) { a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b]; a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6); }
+    a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
+    void* d_y; int rc = api_scratch(3, L.n_sym + 64, &d_y); if (rc) return rc;
+    a.ystream = (uint8_t*)d_y;
+    int occ = 1; rc = occupancy_of((const void*)decode_stream_kernel, 512, a.lds_bytes, &occ); if (rc) return rc;
+    {
+        const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(a.n_tiles, (uint32_t)(api_n_cu() * occ)));
+        void* args[] = {(void*)&a};
+        HIPCHK(hipLaunchKernel((const void*)decode_stream_kernel, dim3(grid), dim3(512), args, a.lds_bytes, s));
+    }
+    EmitStArgs e; memset(&e, 0, sizeof e);
+    e.ystream = (const uint8_t*)d_y; e.n_sym = (uint32_t)L.n_sym; e.out = d_out; e.n_units = units;
+    e.span = 52u * 512u; e.n_steps = (uint32_t)((L.n_sym + e.span - 1) / e.span);
+    e.il_on = il ? 1 : 0;
+    if (il) {
+        const uint64_t A = (uint64_t)cfg.tile_w * cfg.tile_h;
+        e.il_w = cfg.tile_w; e.il_A = (uint32_t)std::min<uint64_t>(A, L.n_sym);
+        e.div_A = to_dev(fastdiv(e.il_A)); e.div_w = to_dev(fastdiv(e.il_w));
+        e.il_fast = (e.il_w % 16u == 0 && (e.il_A % 16u == 0 || e.il_A == L.n_sym)) ? 1 : 0;
+    }
+    e.sym_off = 0; e.o_off = (e.span + 2u * e.il_w + 64u + 15u) & ~15u;
+    e.lds_bytes = e.o_off + (to_pixels ? 0u : (e.span / 26u) * 27u + 64u);
+    const void* fn = to_pixels ? (const void*)emit_stream_kernel<true> : (const void*)emit_stream_kernel<false>;
+    rc = occupancy_of(fn, 512, e.lds_bytes, &occ); if (rc) return rc;
+    {
+        const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(e.n_steps, (uint32_t)(api_n_cu() * occ)));
+        void* args[] = {(void*)&e};
+        HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(512), args, e.lds_bytes, s));
+    }
+    return T3_OK;
+}
+
 // body decode with a known config (header already parsed)
 int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_raw, const uint8_t next[3],
                 void* d_out, uint64_t cap_units, uint64_t* n_out, int to_pixels, uint32_t* d_fail, hipStream_t s) {
@@ -132,8 +226,17 @@ int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_r
         for (int b = 0; b < 9; ++b) { a.band_k[b] = L.band_k[b]; a.band_blocks[b] = L.band_blocks[b]; a.band_first[b] = total; a.band_off[b] = L.band_body_off[b]; total += L.band_blocks[b]; }
         use_syms = L.n_sym; n_words = n_raw;
         const uint64_t funits = to_pixels ? 2 * n_words : n_words;
-        if (funits <= cap_units && (!to_pixels || ((uintptr_t)d_out & 15u) == 0) && getenv("T3HIP_GENERIC_DECODE") == nullptr) {
-            const int frc = decode_fixed_fused(d_in, n_in, cfg, L, sc, d_out, funits, to_pixels, d_fail, s);
+        if (funits <= cap_units && (!to_pixels || ((uintptr_t)d_out & 15u) == 0) && getenv("T3HIP_GENERIC_DECODE") == nullptr && 9 * n_in < (1ull << 32)) {
+            // a beacon is stripped first (its own pass); then the fully fused kernel where it applies, else the two-kernel path
+            const uint8_t* body = (const uint8_t*)d_in; uint64_t body_bytes = 9 * n_in; uint32_t hs = L.header_syms;
+            if (L.beacon_on) {
+                void* d_b; int brc = api_scratch(2, L.body_syms + 64, &d_b); if (brc) return brc;
+                DebeaconArgs d; d.framed = (const uint8_t*)d_in + L.header_syms; d.framed_bytes = 9 * n_in - L.header_syms; d.body = (uint8_t*)d_b; d.body_syms = L.body_syms; d.period = cfg.beacon_words_period; d.slot = cfg.beacon_band_slot;
+                if (L.body_syms) { hipLaunchKernelGGL(debeacon_kernel, dim3(grid_for((L.body_syms + 15) / 16, 256)), dim3(256), 0, s, d); HIPCHK(hipGetLastError()); }
+                body = (const uint8_t*)d_b; body_bytes = L.body_syms; hs = 0;
+            }
+            int frc = decode_fixed_fused(body, body_bytes, hs, L, sc, d_out, funits, to_pixels, d_fail, s);
+            if (frc == 1) frc = decode_fixed_stream(body, body_bytes, hs, cfg, L, sc, d_out, funits, to_pixels, d_fail, s);
             if (frc == T3_OK) { *n_out = funits; return T3_OK; }
             if (frc < 0) return frc;
         }

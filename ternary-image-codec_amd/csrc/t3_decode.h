@@ -65,11 +65,42 @@ struct DecFxArgs {
     uint32_t y_off, o_off, lds_bytes;
 };
 
+// Two-kernel FIXED decoder for the framings the fully fused kernel does not take (mixed k, 2-D interleave; a beacon is
+// stripped by a pre-pass): D1-D4 as above with the bands grouped by k (whole waves per group), corrected data symbols to a
+// stream-ordered scratch; then symbols [through the de-interleave map] -> units.  (t3_decode_stream.hip)
+constexpr int kStMaxGrp = 4;
+struct DecStArgs {
+    const uint8_t* in; uint64_t in_bytes;      // coded body (hdr_syms symbols of header in front)
+    uint8_t* ystream;                          // scratch: n_sym corrected data symbols in stream order
+    uint32_t* fail;
+    const FxTables* tab; const uint8_t* fma; uint32_t fma_off;
+    struct Grp { uint32_t r, nb, n_items, wave0, n_waves, lut_off, lut_bytes; const uint32_t* lut; const uint32_t* roots; uint8_t bands[12]; } grp[kStMaxGrp];
+    uint32_t n_grp, n_slots;                   // wave slots of a tile: group g owns [wave0, wave0 + n_waves)
+    uint32_t n_tiles, TS;                      // TS = 9 Lq stream symbols per tile, Lq = nb_g k_g for every group
+    uint32_t n_sym, hdr_syms;
+    uint32_t band_blocks[9]; uint64_t band_body_off[9]; uint32_t band_boff6[9];
+    uint32_t cyc24, pre0, pre1;
+    uint32_t y_off, lds_bytes;
+};
+struct EmitStArgs {
+    const uint8_t* ystream; uint32_t n_sym;    // 16-byte aligned
+    void* out; uint64_t n_units;               // pixels or words
+    uint32_t span;                             // symbols per workgroup step (multiple of 52 x lanes resp. 26 x lanes)
+    uint32_t n_steps;
+    uint32_t il_on, il_w, il_A, il_fast;       // il_fast: rows and chunks are multiples of 16 symbols -> granule-wise permutation
+    DevDiv div_A, div_w;
+    uint32_t sym_off, o_off, lds_bytes;
+};
+struct DebeaconArgs { const uint8_t* framed; uint64_t framed_bytes; uint8_t* body; uint64_t body_syms; uint32_t period, slot; };   // framed_bytes: readable bytes from `framed`
+
 int decode_init(const RsTables* d_tab);
 
 #if defined(__HIPCC__)
 __global__ void dec_gather_rs_kernel(const DecArgs a);
 template <int R, bool TO_PIXELS> __global__ void decode_fixed_kernel(const DecFxArgs a);
+__global__ void decode_stream_kernel(const DecStArgs a);
+template <bool TO_PIXELS> __global__ void emit_stream_kernel(const EmitStArgs a);
+__global__ void debeacon_kernel(const DebeaconArgs a);
 __global__ void dec_emit_kernel(const EmitArgs a);
 __global__ void rs_decode_blocks_kernel(uint8_t* code, uint64_t n_blocks, int k, int fixed, const RsTables* tab, uint8_t* data, uint8_t* ok);
 __global__ void inject_errors_kernel(uint8_t* syms, uint64_t n_blocks, uint32_t seed, int max_err);

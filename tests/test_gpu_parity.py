@@ -254,6 +254,8 @@ def test_fixed_mode_roundtrip_with_errors(gpu, orc, name):
         oseen = ol.make_cfg(mode=1)
         rc, oback = orc.decode_frame(bad, oseen)
         assert rc == 0 and np.array_equal(oback, back)
+        okr, rawback = gpu.decode_profile_to_raw(bad, gpu.DecoderContext(mode=1))      # the same stream to 26-trit words
+        assert okr and np.array_equal(np.asarray(rawback).reshape(-1), np.asarray(orc.pack_pixels(padded)).reshape(-1)), (name, n)
         seen = dctx.cfg_last_seen.as_dict(); want_seen = oseen.as_dict()
         assert {k: v for k, v in seen.items()} == {k: v for k, v in want_seen.items()}
         # too many errors in one block -> detected, reference-style `false`
@@ -397,3 +399,36 @@ def test_encode_frame_random_configurations(gpu, orc, mode):
             okd, back = gpu.decode_frame(enc, gpu.DecoderContext(mode=1))
             red = orc.unpack_words(orc.pack_pixels(px))          # what survives the trit packing of out-of-range values
             assert okd and np.array_equal(back[: len(red)].view(np.uint8), red.view(np.uint8)), (trial, kw, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["p2_luma", "p5_tile64_luma", "p5_tile7x5_mixed4", "p2_beacon83", "p1_beacon3_slot8", "p3_uniform20"])
+def test_fixed_decode_paths_agree(gpu, orc, name):
+    """The fused / two-kernel FIXED decoders (t3_decode_fused.hip, t3_decode_stream.hip) against the generic gather kernels
+    (T3HIP_GENERIC_DECODE=1) on the same corrupted stream, at a size of many tiles: pixels, raw words and the verdict."""
+    rng = np.random.default_rng(zlib.crc32(name.encode()) + 77)
+    cfg, ocfg = both(gpu, CFGS[name], mode=1)
+    n = 1_000_003
+    px = rand_pixels(rng, n)
+    ok, enc = gpu.encode_frame(px, cfg); assert ok
+    L = gpu.plan((n + 1) // 2, cfg)
+    bad = np.ascontiguousarray(enc).copy().reshape(-1)
+    if not L.beacon_on:
+        bad = np.asarray(orc.inject_errors(enc, L.header_syms, L.body_syms // 26, 99, (26 - max(L.band_k)) // 2)).reshape(-1).copy()
+    else:                                      # framed positions: corrupt a sparse set of symbols (at most one per 26)
+        idx = L.header_syms + 40 * rng.permutation((len(bad) - L.header_syms) // 40)[:20000]
+        bad[idx] = (bad[idx] + 1 + rng.integers(0, 26, len(idx))) % 27
+    bad = bad.reshape(-1, 9)
+    outs = {}
+    for generic in (False, True):
+        if generic: os.environ["T3HIP_GENERIC_DECODE"] = "1"
+        try:
+            okp, back = gpu.decode_frame(bad, gpu.DecoderContext(mode=1))
+            okw, raw = gpu.decode_profile_to_raw(bad, gpu.DecoderContext(mode=1))
+        finally:
+            os.environ.pop("T3HIP_GENERIC_DECODE", None)
+        outs[generic] = (okp, np.asarray(back).view(np.uint8).reshape(-1).copy(), okw, np.asarray(raw).reshape(-1).copy())
+    assert outs[False][0] == outs[True][0] and outs[False][2] == outs[True][2]
+    assert outs[False][0] and np.array_equal(outs[False][1], outs[True][1]) and np.array_equal(outs[False][3], outs[True][3])
+    padded = np.zeros(2 * ((n + 1) // 2), ol.PIXEL_DT); padded[:n] = px
+    assert np.array_equal(outs[False][1], padded.view(np.uint8).reshape(-1))
