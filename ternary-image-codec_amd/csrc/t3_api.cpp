@@ -371,7 +371,7 @@ int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, vo
         b.period = cfg->beacon_words_period; b.slot = cfg->beacon_band_slot;
         b.sym = beacon_symbol(cfg->profile, (uint16_t)(cfg->superframe_words % 5), 0);     // OLD:1130
         b.hdr_syms = hs; b.pad_bytes = pad; memcpy(b.hdr, hdr, sizeof hdr);
-        const unsigned nb = (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, (L.body_syms_framed + 255) / 256), 65536);
+        const unsigned nb = (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, ((hs + L.body_syms_framed + 15) / 16 + 255) / 256), 65536);   // one lane per 16-byte granule
         hipLaunchKernelGGL(beacon_kernel, dim3(nb), dim3(256), 0, s, b);
         HIPCHK(hipGetLastError());
     }

@@ -917,26 +917,50 @@ __global__ __launch_bounds__(1024) void encode_kernel_mixed(const EncArgs a) { e
 T3_INST_K(FE_PIXELS, false) T3_INST_K(FE_PIXELS, true) T3_INST_K(FE_WORDS, false) T3_INST_K(FE_WORDS, true)
 
 // ---------------------------------------------------------------------------------------------------------
-// beacon insertion pass (OLD:1118-1141): gather, one lane per framed byte
+// beacon insertion pass (OLD:1118-1141): framed[q] = beacon symbol at slot `slot` of every period-th word, else
+// body[q - #beacons before q], zero past the body.  One lane = one 16-byte granule of the output frame: between two
+// beacons that is a shifted copy (aligned dword loads + funnel shifts, one 16-byte store); a granule that holds a beacon
+// or touches the header / the end of the body goes byte by byte.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void beacon_kernel(const BeaconArgs a) {
-    const uint64_t q0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q0 == 0) {
+    const uint64_t g0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g0 == 0) {
         for (uint32_t i = 0; i < a.hdr_syms; ++i) a.frame_out[i] = a.hdr[i];
         for (uint32_t i = 0; i < a.pad_bytes; ++i) a.frame_out[a.hdr_syms + a.framed_syms + i] = 0;
     }
-    for (uint64_t q = q0; q < a.framed_syms; q += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t w = q / 9u; const uint32_t slot = (uint32_t)(q - 9u * w);
-        const bool hitw = (w % a.period) == 0;
-        uint8_t v;
-        if (hitw && slot == a.slot) v = (uint8_t)a.sym;
-        else {
-            uint64_t nb = 0;                                   // beacons strictly before q
-            if (a.slot < 9u) nb = (w + a.period - 1u) / a.period + ((hitw && a.slot < slot) ? 1u : 0u);
-            const uint64_t kq = q - nb;
-            v = kq < a.body_syms ? a.body[kq] : 0;
+    const uint64_t cyc = 9ull * a.period;
+    const uint64_t end = a.hdr_syms + a.framed_syms;
+    const bool small = end < (1ull << 32) && cyc < (1ull << 32);                  // 32-bit divisions where the frame allows
+    auto before = [&](uint64_t q) -> uint64_t {                                    // beacons strictly before q
+        if (a.slot >= 9u || q <= a.slot) return 0u;
+        return small ? (uint64_t)(((uint32_t)q - a.slot - 1u) / (uint32_t)cyc + 1u) : (q - a.slot - 1u) / cyc + 1u;
+    };
+    for (uint64_t g = g0; 16 * g < end; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t B0 = 16 * g;
+        if (B0 >= a.hdr_syms && B0 + 16 <= end && ((uintptr_t)a.frame_out & 15u) == 0) {
+            const uint64_t q = B0 - a.hdr_syms, nb = before(q);
+            if (nb == before(q + 16) && q - nb + 20 <= a.body_syms) {
+                const uint8_t* src = a.body + (q - nb);
+                const uint32_t sh = ((uint32_t)(uintptr_t)src & 3u) * 8u;
+                const uint32_t* p = (const uint32_t*)((uintptr_t)src & ~(uintptr_t)3);
+                uint32_t dw[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) dw[i] = p[i];
+                *(uint4*)(a.frame_out + B0) = make_uint4(__builtin_amdgcn_alignbit(dw[1], dw[0], sh), __builtin_amdgcn_alignbit(dw[2], dw[1], sh),
+                                                          __builtin_amdgcn_alignbit(dw[3], dw[2], sh), __builtin_amdgcn_alignbit(dw[4], dw[3], sh));
+                continue;
+            }
         }
-        a.frame_out[a.hdr_syms + q] = v;
+        // byte by byte, no division per byte: the beacons are at slot + j cyc, `nb` of them lie before q
+        const uint64_t Bs = max(B0, (uint64_t)a.hdr_syms), Be = min(B0 + 16, end);
+        uint64_t nb = before(Bs - a.hdr_syms), qb = a.slot < 9u ? a.slot + nb * cyc : ~0ull;
+        for (uint64_t B = Bs; B < Be; ++B) {
+            const uint64_t q = B - a.hdr_syms;
+            uint8_t v;
+            if (q == qb) { v = (uint8_t)a.sym; ++nb; qb += cyc; }
+            else { const uint64_t kq = q - nb; v = kq < a.body_syms ? a.body[kq] : 0; }
+            a.frame_out[B] = v;
+        }
     }
 }
 
