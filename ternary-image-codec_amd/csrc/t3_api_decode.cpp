@@ -25,6 +25,7 @@ using namespace t3;
 namespace {
 uint32_t* d_zpow = nullptr;     // CRC "append 2^j zero bytes" operators
 uint32_t* d_crc_acc = nullptr;  // [0] xor accumulator, [1] symbol sum
+uint32_t* d_crc_afrag = nullptr; // bit-matrix slices of the matrix-core CRC (t3_crc_mfma.hip)
 FxTables* d_fxtab = nullptr;    // field tables of the fused FIXED decoder
 uint32_t* d_synd_lut[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t synd_lut_bytes[4] = {0, 0, 0, 0};   // per k index
 uint8_t* d_fma = nullptr;       // fma[x][y][a] = a + x y: one table read per multiply-accumulate of the corrector
@@ -286,6 +287,19 @@ int decode_init(const RsTables*) {
     HIPCHK(hipMalloc((void**)&d_zpow, z.size() * 4));
     HIPCHK(hipMemcpy(d_zpow, z.data(), z.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&d_crc_acc, 64));
+    {   // matrix-core CRC: column (step s, lane half kh, dword d, byte t) of the bit matrix = the remainder, at the end of a 64-byte
+        // chunk, of the single input bit that K slot carries; rows = register bits.  Lane l = m + 32 kh holds row m (t3_host.cpp build_mfma_encode)
+        auto adv = [&](uint32_t r, uint32_t nzero) { while (nzero--) r = tbl[r & 0xFF] ^ (r >> 8); return r; };
+        std::vector<uint32_t> af((size_t)22 * 64 * 4, 0u);
+        for (int st = 0; st < 22; ++st) for (int kh = 0; kh < 2; ++kh) for (int d = 0; d < 4; ++d) for (int t = 0; t < 4; ++t) {
+            uint32_t vec;
+            if (st < 16) { const int bit = 4 * d + t, byte = 2 * st + (bit >> 3), o = 32 * kh + byte; vec = adv(tbl[1u << (bit & 7)], 63u - (uint32_t)o); }
+            else vec = adv(1u << (8 * d + 4 * kh + t), st == 16 ? 2048u : 64u << (st - 17));   // 16: the running remainder 2048 bytes further on; 17..21: 64 * 2^b
+            for (int m = 0; m < 32; ++m) if (vec >> m & 1u) af[((size_t)st * 64 + m + 32 * kh) * 4 + d] |= 1u << (8 * t);
+        }
+        HIPCHK(hipMalloc((void**)&d_crc_afrag, af.size() * 4));
+        HIPCHK(hipMemcpy(d_crc_afrag, af.data(), af.size() * 4, hipMemcpyHostToDevice));
+    }
     {   // field tables of the fused decoder
         const Field& F = field();
         static const uint8_t want_exp[26] = {1, 3, 9, 5, 15, 23, 13, 17, 20, 4, 12, 14, 11, 2, 6, 18, 7, 21, 16, 26, 22, 10, 8, 24, 25, 19};
@@ -386,6 +400,33 @@ int t3hip_inject_errors_dev(void* d_words, uint64_t first_sym, uint64_t n_blocks
     HIPCHK(hipGetLastError()); return T3_OK;
 }
 
+// CRC + symbol-sum accumulation of a payload into acc[0] / acc[1] (zeroed here): whole 2 KiB rounds on the matrix cores
+// when the buffer is 16-byte aligned, the rest (or everything) through the table kernel
+static int launch_crc(const uint8_t* d_data, uint64_t n_bytes, uint32_t* acc, hipStream_t s) {
+    HIPCHK(hipMemsetAsync(acc, 0, 8, s));
+    uint64_t done = 0;
+    static const int rpw_env = [] { const char* e = getenv("T3HIP_CRC_ROUNDS_PER_WAVE"); return e ? atoi(e) : 0; }();
+    if (((uintptr_t)d_data & 15u) == 0 && n_bytes >= 64 * 2048 && (n_bytes >> 11) < (1ull << 32) && getenv("T3HIP_CRC_TABLES") == nullptr) {
+        CrcMArgs m; memset(&m, 0, sizeof m);
+        m.data = d_data; m.n_bytes = n_bytes; m.n_rounds = (uint32_t)(n_bytes >> 11);
+        // one 16-wave workgroup per CU (four waves per SIMD, all resident at once), at least 8 rounds per wave
+        const uint64_t slots = (uint64_t)api_n_cu() * 16;
+        m.rounds_per_wave = rpw_env > 0 ? (uint32_t)rpw_env : (uint32_t)std::max<uint64_t>(8, (m.n_rounds + slots - 1) / slots);
+        m.afrag = d_crc_afrag; m.zpow = d_zpow; m.chunk_crc = acc; m.sym_sum = acc + 1;
+        const uint64_t waves = ((uint64_t)m.n_rounds + m.rounds_per_wave - 1) / m.rounds_per_wave;
+        hipLaunchKernelGGL(crc_mfma_kernel, dim3((unsigned)((waves + 15) / 16)), dim3(1024), 0, s, m); HIPCHK(hipGetLastError());
+        done = (uint64_t)m.n_rounds << 11;
+    }
+    if (done < n_bytes) {
+        CrcArgs c; memset(&c, 0, sizeof c);
+        c.data = d_data + done; c.n_bytes = n_bytes - done; c.chunk_bytes = 2304;      // 256 words per lane
+        c.n_chunks = (uint32_t)((c.n_bytes + c.chunk_bytes - 1) / c.chunk_bytes);
+        c.chunk_crc = acc; c.sym_sum = acc + 1; c.zpow = d_zpow;
+        hipLaunchKernelGGL(crc_chunks_kernel, dim3((c.n_chunks + 255) / 256), dim3(256), 0, s, c); HIPCHK(hipGetLastError());
+    }
+    return T3_OK;
+}
+
 uint64_t t3hip_frame_record_scratch_bytes(uint64_t) { return 64; }
 int t3hip_frame_record_dev(const void* d_words, uint64_t n_words, uint64_t frame_idx, const t3_cfg* cfg, t3_frame_record* d_rec,
                            void* d_scratch, uint64_t scratch_bytes, void* stream) {
@@ -393,11 +434,9 @@ int t3hip_frame_record_dev(const void* d_words, uint64_t n_words, uint64_t frame
     if (!cfg || !d_rec || (n_words && !d_words) || !d_scratch || scratch_bytes < 8) return T3_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     CrcArgs c; memset(&c, 0, sizeof c);
-    c.data = (const uint8_t*)d_words; c.n_bytes = 9 * n_words; c.chunk_bytes = 2304;      // 256 words per lane
-    c.n_chunks = (uint32_t)((c.n_bytes + c.chunk_bytes - 1) / c.chunk_bytes);
+    c.data = (const uint8_t*)d_words; c.n_bytes = 9 * n_words;
     c.chunk_crc = (uint32_t*)d_scratch; c.sym_sum = (uint32_t*)d_scratch + 1; c.zpow = d_zpow;
-    HIPCHK(hipMemsetAsync(d_scratch, 0, 8, s));
-    if (c.n_chunks) { hipLaunchKernelGGL(crc_chunks_kernel, dim3((c.n_chunks + 255) / 256), dim3(256), 0, s, c); HIPCHK(hipGetLastError()); }
+    { const int rc = launch_crc(c.data, c.n_bytes, (uint32_t*)d_scratch, s); if (rc) return rc; }
     hipLaunchKernelGGL(frame_record_kernel, dim3(1), dim3(64), 0, s, c, (const uint8_t*)d_words, n_words, frame_idx, (uint32_t)cfg->profile, (uint32_t)cfg->mode, (void*)d_rec);
     HIPCHK(hipGetLastError()); return T3_OK;
 }
@@ -408,12 +447,7 @@ int t3hip_crc32_dev(const void* d_data, uint64_t n_bytes, uint32_t* crc_out, voi
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::recursive_mutex> lk(g_mail_mu);                       // one scratch accumulator per process
     void* d_sc = d_crc_acc;
-    CrcArgs c; memset(&c, 0, sizeof c);
-    c.data = (const uint8_t*)d_data; c.n_bytes = n_bytes; c.chunk_bytes = 2304;
-    c.n_chunks = (uint32_t)((n_bytes + c.chunk_bytes - 1) / c.chunk_bytes);
-    c.chunk_crc = (uint32_t*)d_sc; c.sym_sum = (uint32_t*)d_sc + 1; c.zpow = d_zpow;
-    HIPCHK(hipMemsetAsync(d_sc, 0, 8, s));
-    if (c.n_chunks) { hipLaunchKernelGGL(crc_chunks_kernel, dim3((c.n_chunks + 255) / 256), dim3(256), 0, s, c); HIPCHK(hipGetLastError()); }
+    { const int rc = launch_crc((const uint8_t*)d_data, n_bytes, (uint32_t*)d_sc, s); if (rc) return rc; }
     uint32_t acc = 0;
     HIPCHK(hipMemcpyAsync(&acc, d_sc, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -40,6 +40,15 @@ struct CrcArgs {
     const uint32_t* zpow;                        // [kCrcPows][32] operator columns (device)
 };
 
+// CRC-32 on the matrix cores (t3_crc_mfma.hip): whole 2 KiB rounds of a 16-byte aligned stream; the tail goes to crc_chunks_kernel
+struct CrcMArgs {
+    const uint8_t* data; uint64_t n_bytes;       // whole stream (distance to its end)
+    uint32_t n_rounds, rounds_per_wave;          // 2 KiB rounds in total / per wave
+    const uint32_t* afrag;                       // [22][64][4]: 16 data slices, the feedback slice, five "append 64 * 2^b bytes" slices, in MFMA lane order
+    const uint32_t* zpow;
+    uint32_t* chunk_crc; uint32_t* sym_sum;
+};
+
 // Fused FIXED-mode decoder (uniform k, 1-D, no beacon): one tile = 9 bands x nb blocks -> a word-aligned slice of the
 // output (27 * Lq trits, Lq = nb * k a multiple of 26).  LDS: [band rows][FxTables][syndrome LUT][symbols Y][out staging].
 struct FxTables {                 // field tables the in-kernel corrector indexes (LDS resident)
@@ -105,6 +114,7 @@ __global__ void dec_emit_kernel(const EmitArgs a);
 __global__ void rs_decode_blocks_kernel(uint8_t* code, uint64_t n_blocks, int k, int fixed, const RsTables* tab, uint8_t* data, uint8_t* ok);
 __global__ void inject_errors_kernel(uint8_t* syms, uint64_t n_blocks, uint32_t seed, int max_err);
 __global__ void crc_chunks_kernel(const CrcArgs a);
+__global__ void crc_mfma_kernel(const CrcMArgs a);
 __global__ void frame_record_kernel(const CrcArgs a, const uint8_t* words, uint64_t n_words, uint64_t frame_idx, uint32_t profile, uint32_t mode, void* rec);
 #endif
 

@@ -118,11 +118,13 @@ def test_device_crc32_vs_zlib():
     rng = np.random.default_rng(5)
     big = rng.integers(0, 256, size=3_000_003, dtype=np.uint8)
     d = torch.from_numpy(big).cuda(); s = torch.cuda.current_stream().cuda_stream
-    for n in (0, 1, 8, 9, 15, 16, 17, 2303, 2304, 2305, 4608, 65536, 589_824 + 5, 3_000_003):
+    # >= 128 KiB on an aligned buffer: whole 2 KiB rounds on the matrix cores + a table-kernel tail; below, or misaligned: tables only
+    for n in (0, 1, 8, 9, 15, 16, 17, 2303, 2304, 2305, 4608, 65536, 131071, 131072, 131073, 262144, 589_824 + 5, 2_999_296, 3_000_003):
         assert t3.crc32_dev(d.data_ptr(), n, s) == zlib.crc32(big[:n].tobytes()), n
         assert t3.crc32(big[:n]) == zlib.crc32(big[:n].tobytes()), n
-    for off in (1, 2, 3, 4, 7, 9, 13):                                     # misaligned starts take the byte path
+    for off in (1, 2, 3, 4, 7, 9, 13, 16, 48):                             # misaligned starts take the byte path
         assert t3.crc32_dev(d.data_ptr() + off, 100_000, s) == zlib.crc32(big[off:off + 100_000].tobytes()), off
+        assert t3.crc32_dev(d.data_ptr() + off, 2_000_001, s) == zlib.crc32(big[off:off + 2_000_001].tobytes()), off
 
 
 @pytest.mark.gpu
