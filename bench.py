@@ -8,7 +8,11 @@ One step = one synthetic 8K (7680x4320) frame through the hot path on each rank,
   1. fused encode, COMPAT arithmetic, P3 / RS(26,20) on all 9 bands, 1-D (BASELINE configs[1]; output hash pinned to the
      reference's b6c43f2f4aa44763),
   2. decode of the same frame's FIXED-mode (v6c) stream carrying 0..3 injected symbol errors in every RS block
-     (BASELINE configs[4] semantics; exact recovery of the pixels is asserted after the timed region),
+     (BASELINE configs[4] semantics; exact recovery of the pixels is asserted after the timed region).  The stream's first
+     frame is decoded before the timed region through the synchronous, reference-shaped entry (header read back and
+     parsed on the host); the timed frames use the streaming entry t3hip_decode_frame_async: body decode launched with
+     the configuration last seen, header symbols checked on the device, verdict words read inside the timed region
+     after the last step (--sync-decode times the synchronous entry for every frame instead),
   3. the frame's index record (CRC-32 + header symbols) for the T3V-style super-frame index; it depends only on step 1 and
      runs on a second HIP stream under the decode (--serial puts it back on the main stream).
 Frames are independent, so ranks shard them with no data-path collective (weak scaling); the only exchange is one
@@ -70,6 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--encode-only", action="store_true", help="profiling aid: skip decode + index in the loop")
     ap.add_argument("--serial", action="store_true", help="index record on the main stream instead of overlapping it with the decode")
+    ap.add_argument("--sync-decode", action="store_true", help="every frame through the synchronous decode entry (host-parsed header, two synchronisations per frame)")
     ap.add_argument("--no-verify", action="store_true", help="profiling aid for timing-only ablation builds (results are wrong by construction)")
     args = ap.parse_args()
 
@@ -111,6 +116,12 @@ def main():
     t3.encode_frame_dev(d_px.data_ptr(), NPX, fcfg, d_fenc.data_ptr(), n_fenc, stream)
     t3.inject_errors_dev(d_fenc.data_ptr(), L.header_syms, L.body_syms // 26, 777 + rank, 3, stream)
     torch.cuda.synchronize()
+    # the stream's first frame: synchronous entry, header parsed on the host -> the configuration the following frames are decoded with
+    dctx = t3.DecoderContext(mode=t3.MODE_FIXED)
+    rc0, n0 = t3.decode_profile_dev(d_fenc.data_ptr(), n_fenc, dctx.cfg_last_seen, d_back.data_ptr(), NPX, True, stream)
+    assert args.no_verify or (rc0 == 0 and n0 == NPX), (rc0, n0)
+    d_verdict = torch.zeros((max(args.steps, args.warmup, 1), 2), dtype=torch.int32, device=dev)
+    d_back.zero_()
 
     def step(i, ev=None):
         if s2 is not None:
@@ -126,9 +137,13 @@ def main():
         if s2 is not None:
             enc_done.record(cur); s2.wait_event(enc_done)
             t3.frame_record_dev(*rec_args, s2.cuda_stream); rec_done.record(s2)
-        seen = t3.DecoderContext(mode=t3.MODE_FIXED).cfg_last_seen
-        rc, n = t3.decode_profile_dev(d_fenc.data_ptr(), n_fenc, seen, d_back.data_ptr(), NPX, True, stream)
-        assert args.no_verify or (rc == 0 and n == NPX), (rc, n)
+        if args.sync_decode:
+            seen = t3.DecoderContext(mode=t3.MODE_FIXED).cfg_last_seen
+            rc, n = t3.decode_profile_dev(d_fenc.data_ptr(), n_fenc, seen, d_back.data_ptr(), NPX, True, stream)
+            assert args.no_verify or (rc == 0 and n == NPX), (rc, n)
+        else:
+            n = t3.decode_frame_async(d_fenc.data_ptr(), n_fenc, dctx.cfg_last_seen, NPX // 2, d_back.data_ptr(), NPX, d_verdict[i % len(d_verdict)].data_ptr(), True, stream)
+            assert n == NPX
         if ev is not None:
             ev[2].record(stream)
         if s2 is None:
@@ -151,6 +166,9 @@ def main():
     if world > 1 and not args.encode_only:
         gathered = sf.gather_records(d_recs)               # the one exchange step: super-frame index records (RCCL all-gather)
     torch.cuda.synchronize()
+    if not args.encode_only and not args.sync_decode:      # the streaming entry's verdicts: header as expected, no uncorrectable block
+        verdicts = d_verdict[: args.steps].cpu().numpy()
+        assert args.no_verify or not verdicts.any(), verdicts
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -188,7 +206,7 @@ def main():
         "metric": "Mpix/s encode+decode 8K RS(26,20)", "value": round(world * args.steps * NPX / dt / 1e6, 3), "unit": "Mpix/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "one 7680x4320 frame per rank per step (BASELINE configs[1]): fused encode COMPAT P3 RS(26,20) 1-D, then FIXED-mode decode of the same frame with 0..3 injected symbol errors per block, then index record" + (" [encode only]" if args.encode_only else ""),
+        "config": {"workload": "one 7680x4320 frame per rank per step (BASELINE configs[1]): fused encode COMPAT P3 RS(26,20) 1-D, then FIXED-mode decode of the same frame with 0..3 injected symbol errors per block (" + ("synchronous entry, header parsed on the host per frame" if args.sync_decode else "streaming entry: configuration from the stream's first frame, header symbols checked on the device") + "), then index record" + (" [encode only]" if args.encode_only else ""),
                    "frame_px": NPX, "coded_words": n_enc, "sharding": "frames per rank, no data-path collective; one all-gather of index records per batch"},
         "encode_ms": round(enc_avg, 4), "decode_ms": round(dec_avg, 4),
         "encode_mpix_s": round(NPX / enc_avg / 1e3, 1), "decode_mpix_s": round(NPX / dec_avg / 1e3, 1),
@@ -199,7 +217,7 @@ def main():
     }
     if not args.encode_only:      # the decoder is the longer kernel of the step: same definition, SURVEY 8d decode bytes + 6 B/px
         dec_bytes = 9 * n_fenc + 6 * NPX
-        out["roofline_decode"] = {"kernel": "decode_fixed_kernel<r=6, to_pixels> (+ header read-back and failure-flag sync of the synchronous entry point)",
+        out["roofline_decode"] = {"kernel": "decode_fixed_kernel<r=6, to_pixels>" + (" (+ header read-back and failure-flag sync of the synchronous entry point)" if args.sync_decode else " (+ header check kernel; the index record's CRC kernel runs beside it)"),
                                   "bound": "hbm", "achieved": round(dec_bytes / (dec_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(dec_bytes / (dec_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                                   "algorithmic_bytes_per_launch": dec_bytes, "launch_ms": round(dec_avg, 4)}

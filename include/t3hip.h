@@ -178,6 +178,18 @@ int t3hip_decode_body_dev(const void* d_in9, uint64_t n_in, const t3_cfg* cfg, u
                           void* d_out, uint64_t cap_units, uint64_t* n_out, int to_pixels,
                           uint32_t* d_fail, void* stream);
 
+/* Streaming decode, no synchronisation.  Frames of one stream repeat their configuration — the reference keeps it in
+ * DecoderContext::cfg_last_seen (OLD:1006-1013) — so a caller that has parsed one frame's header (t3hip_decode_profile_dev
+ * / t3hip_read_header_dev) decodes the following frames with that configuration: the body kernels are launched at once,
+ * and a device-side check compares the frame's header symbols with the header `cfg` / `n_raw_words` encode to
+ * (header RS + CRC-12, OLD:1142-1162).  Device words, zeroed and written by the call on `stream`:
+ *   d_verdict[0] = 1 if the header differs (another configuration, or symbols that need the header's RS correction):
+ *                  the output is then meaningless and the frame goes through t3hip_decode_profile_dev;
+ *   d_verdict[1] = number of uncorrectable RS blocks (the reference's `false`, OLD:987).                          */
+int t3hip_decode_frame_async(const void* d_in9, uint64_t n_in, const t3_cfg* cfg, uint64_t n_raw_words,
+                             void* d_out, uint64_t cap_units, uint64_t* n_out, int to_pixels,
+                             uint32_t* d_verdict, void* stream);
+
 /* ---- block-level RS(26,k) (RSCodec::encode_block OLD:517-535, decode_block OLD:546-662) */
 int t3hip_rs_encode_blocks_dev(int k, int mode, const uint8_t* d_data_k, uint64_t n_blocks,
                                uint8_t* d_code26, void* stream);

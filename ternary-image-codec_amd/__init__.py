@@ -450,6 +450,15 @@ def decode_body_dev(d_in, n_in, cfg, n_raw, d_out, cap_units, d_fail, to_pixels=
     return n.value
 
 
+def decode_frame_async(d_in, n_in, cfg, n_raw, d_out, cap_units, d_verdict, to_pixels=True, stream=0):
+    """Streaming decode with a known configuration, no synchronisation; d_verdict -> two device uint32: [0] header differs,
+    [1] uncorrectable blocks.  Returns the unit count the launch will produce."""
+    n = C.c_uint64()
+    _chk(lib().t3hip_decode_frame_async(C.c_void_p(d_in), C.c_uint64(n_in), C.byref(cfg), C.c_uint64(n_raw), C.c_void_p(d_out), C.c_uint64(cap_units), C.byref(n),
+                                        C.c_int(1 if to_pixels else 0), C.c_void_p(d_verdict), C.c_void_p(stream)), "t3hip_decode_frame_async")
+    return n.value
+
+
 def rs_encode_blocks_dev(k, mode, d_data, n_blocks, d_code, stream=0):
     _chk(lib().t3hip_rs_encode_blocks_dev(C.c_int(k), C.c_int(mode), C.c_void_p(d_data), C.c_uint64(n_blocks), C.c_void_p(d_code), C.c_void_p(stream)), "t3hip_rs_encode_blocks_dev")
 

@@ -332,6 +332,36 @@ int t3hip_decode_body_dev(const void* d_in, uint64_t n_in, const t3_cfg* cfg, ui
     return decode_body(d_in, n_in, *cfg, n_raw, sc.next, d_out, cap, n_out, to_pixels, d_fail, (hipStream_t)stream);
 }
 
+int t3hip_decode_frame_async(const void* d_in, uint64_t n_in, const t3_cfg* cfg, uint64_t n_raw, void* d_out, uint64_t cap, uint64_t* n_out,
+                             int to_pixels, uint32_t* d_verdict, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!cfg || !n_out || !d_verdict || (n_in && !d_in) || cfg->profile == T3_RAW_MODE) return T3_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t hdr[96]; memset(hdr, 0, sizeof hdr);
+    t3_layout L; int rc = plan(n_raw, *cfg, L); if (rc) return rc;
+    const uint32_t hs = (uint32_t)header_encode(*cfg, n_raw, hdr);
+    if (9 * n_in < hs) return T3_E_HEADER;
+    // the expected header symbols live on the device, one small buffer per distinct header ever asked for (a stream has one)
+    const uint8_t* d_exp = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_tab_mu);
+        static std::map<std::vector<uint8_t>, uint8_t*> known;
+        std::vector<uint8_t> key(hdr, hdr + 96);
+        auto it = known.find(key);
+        if (it == known.end()) {
+            if (known.size() >= 256) return T3_E_ARG;                           // not a stream any more: use the synchronous entry
+            uint8_t* d = nullptr; HIPCHK(hipMalloc((void**)&d, 96)); HIPCHK(hipMemcpy(d, hdr, 96, hipMemcpyHostToDevice));
+            it = known.emplace(std::move(key), d).first;
+        }
+        d_exp = it->second;
+    }
+    HIPCHK(hipMemsetAsync(d_verdict, 0, 8, s));
+    hipLaunchKernelGGL(hdr_compare_kernel, dim3(1), dim3(128), 0, s, (const uint8_t*)d_in, d_exp, hs, d_verdict);
+    HIPCHK(hipGetLastError());
+    const ScrCycle sc = scrambler_cycle(cfg->seed_a, cfg->seed_b, cfg->seed_s0);
+    return decode_body(d_in, n_in, *cfg, n_raw, sc.next, d_out, cap, n_out, to_pixels, d_verdict + 1, s);
+}
+
 int t3hip_decode_profile_dev(const void* d_in, uint64_t n_in, t3_cfg* seen, void* d_out, uint64_t cap, uint64_t* n_out, int to_pixels, void* stream) {
     if (!api_ready()) return T3_E_NODEVICE;
     if (!seen || !n_out || (n_in && !d_in)) return T3_E_ARG;
@@ -409,12 +439,15 @@ static int launch_crc(const uint8_t* d_data, uint64_t n_bytes, uint32_t* acc, hi
     if (((uintptr_t)d_data & 15u) == 0 && n_bytes >= 64 * 2048 && (n_bytes >> 11) < (1ull << 32) && getenv("T3HIP_CRC_TABLES") == nullptr) {
         CrcMArgs m; memset(&m, 0, sizeof m);
         m.data = d_data; m.n_bytes = n_bytes; m.n_rounds = (uint32_t)(n_bytes >> 11);
-        // one 16-wave workgroup per CU (four waves per SIMD, all resident at once), at least 8 rounds per wave
-        const uint64_t slots = (uint64_t)api_n_cu() * 16;
+        // Four-wave workgroups, two waves per SIMD over the whole chip: a wave needs ~100 VGPRs (the bit matrix), which is what a
+        // SIMD has left beside the decoder's six waves, so the kernel can start under the decode instead of behind it (16-wave
+        // workgroups had to wait for the decoder's persistent workgroups to drain: +0.1 ms per step).  At least 8 rounds per wave.
+        static const int wps = [] { const char* e = getenv("T3HIP_CRC_WAVES_PER_SIMD"); const int v = e ? atoi(e) : 2; return v > 0 ? v : 2; }();
+        const uint64_t slots = (uint64_t)api_n_cu() * 4 * (uint64_t)wps;
         m.rounds_per_wave = rpw_env > 0 ? (uint32_t)rpw_env : (uint32_t)std::max<uint64_t>(8, (m.n_rounds + slots - 1) / slots);
         m.afrag = d_crc_afrag; m.zpow = d_zpow; m.chunk_crc = acc; m.sym_sum = acc + 1;
         const uint64_t waves = ((uint64_t)m.n_rounds + m.rounds_per_wave - 1) / m.rounds_per_wave;
-        hipLaunchKernelGGL(crc_mfma_kernel, dim3((unsigned)((waves + 15) / 16)), dim3(1024), 0, s, m); HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(crc_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, m); HIPCHK(hipGetLastError());
         done = (uint64_t)m.n_rounds << 11;
     }
     if (done < n_bytes) {

@@ -46,7 +46,7 @@ __device__ __forceinline__ v4i parity_bytes(const v16i& acc) {
     return fb;
 }
 
-__global__ __launch_bounds__(1024) void crc_mfma_kernel(const CrcMArgs a) {
+__global__ __launch_bounds__(256) void crc_mfma_kernel(const CrcMArgs a) {
     __shared__ uint32_t red[2 * 16];
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, kh = lane >> 5, wave = threadIdx.x >> 6;
     const uint32_t wave_g = blockIdx.x * (blockDim.x >> 6) + wave;

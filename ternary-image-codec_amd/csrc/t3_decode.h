@@ -113,6 +113,7 @@ __global__ void debeacon_kernel(const DebeaconArgs a);
 __global__ void dec_emit_kernel(const EmitArgs a);
 __global__ void rs_decode_blocks_kernel(uint8_t* code, uint64_t n_blocks, int k, int fixed, const RsTables* tab, uint8_t* data, uint8_t* ok);
 __global__ void inject_errors_kernel(uint8_t* syms, uint64_t n_blocks, uint32_t seed, int max_err);
+__global__ void hdr_compare_kernel(const uint8_t* in, const uint8_t* expect, uint32_t n, uint32_t* mismatch);
 __global__ void crc_chunks_kernel(const CrcArgs a);
 __global__ void crc_mfma_kernel(const CrcMArgs a);
 __global__ void frame_record_kernel(const CrcArgs a, const uint8_t* words, uint64_t n_words, uint64_t frame_idx, uint32_t profile, uint32_t mode, void* rec);

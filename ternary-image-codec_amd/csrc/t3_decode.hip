@@ -215,6 +215,11 @@ __global__ __launch_bounds__(256) void crc_chunks_kernel(const CrcArgs a) {
     if ((threadIdx.x & 63) == 0) { if (part) atomicXor(a.chunk_crc, part); if (sum) atomicAdd(a.sym_sum, sum); }
 }
 
+// header symbols of the frame against the ones the previous frame parsed to (speculative decode, t3_api_decode.cpp)
+__global__ void hdr_compare_kernel(const uint8_t* in, const uint8_t* expect, uint32_t n, uint32_t* mismatch) {
+    if (threadIdx.x < n && in[threadIdx.x] != expect[threadIdx.x]) *mismatch = 1u;
+}
+
 __global__ void frame_record_kernel(const CrcArgs a, const uint8_t* words, uint64_t n_words, uint64_t frame_idx, uint32_t profile, uint32_t mode, void* recv) {
     t3_frame_record* rec = (t3_frame_record*)recv;
     if (threadIdx.x == 0) {

@@ -432,3 +432,41 @@ def test_fixed_decode_paths_agree(gpu, orc, name):
     assert outs[False][0] and np.array_equal(outs[False][1], outs[True][1]) and np.array_equal(outs[False][3], outs[True][3])
     padded = np.zeros(2 * ((n + 1) // 2), ol.PIXEL_DT); padded[:n] = px
     assert np.array_equal(outs[False][1], padded.view(np.uint8).reshape(-1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["p3_uniform20", "p5_tile64_luma", "p2_beacon83"])
+def test_decode_frame_async_streaming(gpu, orc, name):
+    """t3hip_decode_frame_async: body decode launched with the stream's known configuration, header symbols checked on the
+    device against the header that configuration encodes to.  Same pixels as the synchronous entry; a different header of the
+    same length (another scrambler seed), a header that needs its RS correction, and an uncorrectable block are reported."""
+    import torch
+    rng = np.random.default_rng(31)
+    n = 50_001
+    px = rand_pixels(rng, n)
+    padded = np.zeros(2 * ((n + 1) // 2), ol.PIXEL_DT); padded[:n] = px
+    cfg, ocfg = both(gpu, CFGS[name], mode=1)
+    kw2 = dict(CFGS[name]); kw2["seed"] = (2, 1, 0)
+    cfg2, _ = both(gpu, kw2, mode=1)
+    ok, enc = gpu.encode_frame(px, cfg); assert ok
+    ok, enc2 = gpu.encode_frame(px, cfg2); assert ok and enc2.shape == enc.shape
+    n_raw = (n + 1) // 2; L = gpu.plan(n_raw, cfg)
+    flat = np.ascontiguousarray(enc).reshape(-1)
+    hurt = flat.copy(); hurt[3] = (hurt[3] + 5) % 27
+    dead = flat.copy(); dead[L.header_syms: L.header_syms + 13] = (dead[L.header_syms: L.header_syms + 13] + 1) % 27
+    s = torch.cuda.current_stream().cuda_stream
+    out = torch.zeros(len(padded) * 6 + 64, dtype=torch.uint8, device="cuda"); ver = torch.full((2,), 7, dtype=torch.int32, device="cuda")
+    def run(stream_bytes, to_pixels=True):
+        d = torch.from_numpy(np.ascontiguousarray(stream_bytes).reshape(-1)).cuda()
+        nu = gpu.decode_frame_async(d.data_ptr(), d.numel() // 9, cfg, n_raw, out.data_ptr(), len(padded), ver.data_ptr(), to_pixels, s)
+        torch.cuda.synchronize()
+        return nu, ver.cpu().numpy().tolist()
+    nu, v = run(flat); assert nu == len(padded) and v == [0, 0]
+    assert np.array_equal(out[: len(padded) * 6].cpu().numpy(), padded.view(np.uint8).reshape(-1))
+    nu, v = run(flat, to_pixels=False); assert nu == n_raw and v == [0, 0]
+    assert np.array_equal(out[: n_raw * 9].cpu().numpy(), np.asarray(orc.pack_pixels(padded)).reshape(-1))
+    assert run(np.ascontiguousarray(enc2).reshape(-1))[1][0] == 1
+    assert run(hurt)[1][0] == 1
+    if not L.beacon_on and min(L.band_k) >= 20:
+        okd, _ = gpu.decode_frame(dead.reshape(-1, 9), gpu.DecoderContext(mode=1))
+        v = run(dead)[1]; assert v[0] == 0 and (v[1] >= 1) == (not okd)
