@@ -307,7 +307,7 @@ int decode_init(const RsTables*) {
         FxTables T; memset(&T, 0, sizeof T);
         memcpy(T.mul, F.t.mul, 729); memcpy(T.add, F.t.add, 729); memcpy(T.inv, F.t.inv, 27); memcpy(T.neg, F.t.neg, 27); memcpy(T.exp, F.t.exp, 26);
         for (int x = 0; x < 27; ++x) for (int y = 0; y < 27; ++y) T.sub[x * 27 + y] = F.t.add[x * 27 + F.t.neg[y]];
-        for (int st = 0; st < 3; ++st) for (int c = 0; c < 27; ++c) T.descr[st][c] = (uint8_t)(8 * F.t.add[c * 27 + F.t.neg[13 * st]]);
+        for (int st = 0; st < 3; ++st) for (int c = 0; c < 27; ++c) T.descr[st][c] = (uint8_t)(4 * F.t.add[c * 27 + F.t.neg[13 * st]]);
         HIPCHK(hipMalloc((void**)&d_fxtab, sizeof T));
         HIPCHK(hipMemcpy(d_fxtab, &T, sizeof T, hipMemcpyHostToDevice));
     }

@@ -54,7 +54,7 @@ struct CrcMArgs {
 struct FxTables {                 // field tables the in-kernel corrector indexes (LDS resident)
     uint8_t mul[729], add[729], sub[729];
     uint8_t inv[27], neg[27], exp[26];
-    uint8_t descr[3][32];         // descr[s][c] = 8 * (c - (s,s,s) trit-wise): descrambled symbol, pre-scaled (LUT entry offset)
+    uint8_t descr[3][32];         // descr[s][c] = 4 * (c - (s,s,s) trit-wise): descrambled symbol, pre-scaled (LUT entry offset)
     uint8_t pad_[37];
 };
 static_assert(sizeof(FxTables) == 2400, "FxTables layout");

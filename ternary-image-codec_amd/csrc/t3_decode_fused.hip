@@ -6,8 +6,9 @@
 //
 // One lane = one RS block, blocks dealt linearly over the eight waves.  Per tile:
 //   D1  7 aligned dword loads per lane (blocks are 26 B, 2-byte aligned) -> 26 symbols in registers
-//   D2  descramble through an 81-byte LDS table (result pre-scaled by 8), syndromes through a per-position LUT:
-//       6-bit SWAR trit fields, two conflict-free ds_read_b64 per symbol, one mod-3 fold per block
+//   D2  descramble through an 81-byte LDS table (result pre-scaled by 4), syndromes through a per-position LUT:
+//       6-bit SWAR trit fields in four 27-dword tables (27 consecutive dwords = 27 banks: conflict-free gathers), one mod-3
+//       fold per block
 //   D3  lanes with non-zero syndromes: Berlekamp-Massey (x*B kept shifted, fixed 8-coefficient registers) on a fused
 //       multiply-add table (a + x y, 27^3 bytes in LDS), degree test, Chien search by table (root mask per locator,
 //       global memory), Forney

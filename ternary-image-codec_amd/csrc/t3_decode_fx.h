@@ -166,7 +166,7 @@ __device__ __forceinline__ void fx_block(const FxCtx& cx, const Row rw, const ui
     for (int i = 0; i < 26; ++i) {
         uint32_t base = dbase[i % 6];
         if (i < 2 && first) base = DSC + 32u * (i == 0 ? cx.pre0 : cx.pre1);
-        d8[i] = l8(base + c[i]);                                      // descrambled symbol * 8
+        d8[i] = l8(base + c[i]);                                      // descrambled symbol * 4 (byte offset of its LUT dword)
     }
     uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0;
 #pragma unroll
@@ -175,9 +175,11 @@ __device__ __forceinline__ void fx_block(const FxCtx& cx, const Row rw, const ui
 #else
     for (uint32_t i = 0; i < 26; ++i) {
 #endif
-        const u32x2 A = *T3_LP(const u32x2, lut + i * SLAB + d8[i]);
-        const u32x2 B = *T3_LP(const u32x2, lut + i * SLAB + 256u + d8[i]);
-        acc0 += A.x; acc1 += A.y; acc2 += B.x; acc3 += B.y;
+        // four (five) 27-dword tables per position: 27 consecutive dwords sit in 27 different banks, so these gathers never conflict
+        acc0 += *T3_LP(const uint32_t, lut + i * SLAB + d8[i]);
+        acc1 += *T3_LP(const uint32_t, lut + i * SLAB + 128u + d8[i]);
+        acc2 += *T3_LP(const uint32_t, lut + i * SLAB + 256u + d8[i]);
+        if constexpr (R >= 6) acc3 += *T3_LP(const uint32_t, lut + i * SLAB + 384u + d8[i]);
         if constexpr (R == 8) acc4 += *T3_LP(const uint32_t, lut + i * SLAB + 512u + d8[i]);
         if (i % 9 == 8) { asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "+v"(acc4)); __builtin_amdgcn_sched_barrier(0); }
     }
@@ -203,7 +205,7 @@ __device__ __forceinline__ void fx_block(const FxCtx& cx, const Row rw, const ui
     }
     // data symbols -> stream order (the zero padding of a band's last block is not stored)
 #pragma unroll
-    for (uint32_t p = 0; p < K; ++p) *T3_LP(uint8_t, yb + 9u * p) = (uint8_t)(d8[p] >> 3);
+    for (uint32_t p = 0; p < K; ++p) *T3_LP(uint8_t, yb + 9u * p) = (uint8_t)(d8[p] >> 2);
 #ifdef T3_ABL_DEC_NO_CORRECT
     if (any == 0x7FFFFFFFu) {
 #else

@@ -221,9 +221,7 @@ void build_syndrome_lut(int k, std::vector<uint32_t>& image) {
                 if (j < nmain) for (int q = 0; q < 3; ++q) dw[q] |= (uint32_t)tr[q] << (6 * j);
                 else for (int q = 0; q < 3; ++q) { const int f = 3 * (j - 5) + q; dw[3 + f / 5] |= (uint32_t)tr[q] << (6 * (f % 5)); }
             }
-            sl[2 * c] = dw[0]; sl[2 * c + 1] = dw[1];
-            sl[64 + 2 * c] = dw[2]; sl[64 + 2 * c + 1] = dw[3];
-            if (r == 8) { sl[128 + 2 * c] = dw[4]; sl[128 + 2 * c + 1] = 0; }
+            for (int q = 0; q < (r == 8 ? 5 : 4); ++q) sl[32 * q + c] = dw[q];    // table q of the position: 27 dwords (128-byte pitch)
         }
     }
 }
