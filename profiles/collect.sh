@@ -5,6 +5,7 @@
 #   3. rocprofv3 --kernel-trace --stats of bench.py   -> gpurun_out/<tag>_kernel_stats.csv (record overlapped with decode, as benched)
 #      and of bench.py --serial                       -> gpurun_out/<tag>_kernel_stats_serial.csv (every kernel alone); no counters in these passes
 #   4. PMC passes on the encode kernel (own passes)   -> gpurun_out/pmc_<tag>_summary.json + gpurun_out/<tag>_pmc_encode_latest.json
+#      and on the decoder / CRC kernels               -> gpurun_out/pmcd_<tag>_summary.json
 # Copy what is to be kept into profiles/ afterwards.
 cd "$(dirname "$0")/.."; export TMPDIR=/tmp
 tag=${1:-x}
@@ -16,6 +17,7 @@ cp gpurun_out/${tag}_kt/kt_kernel_stats.csv gpurun_out/${tag}_kernel_stats.csv 2
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_kts -o kt --output-format csv -- python3 bench.py --serial --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/${tag}_kts.log 2>&1
 cp gpurun_out/${tag}_kts/kt_kernel_stats.csv gpurun_out/${tag}_kernel_stats_serial.csv 2>/dev/null; head -6 gpurun_out/${tag}_kernel_stats_serial.csv | cut -c1-160
 bash profiles/pmc_encode.sh ${tag} > gpurun_out/${tag}_pmc.txt 2>&1
+bash profiles/pmc_decode.sh ${tag} > gpurun_out/${tag}_pmcd.txt 2>&1      # SQ counters of the decoder / CRC kernels -> gpurun_out/pmcd_${tag}_summary.json
 python3 - <<PY
 import json
 p = json.load(open('gpurun_out/pmc_${tag}_summary.json'))

@@ -14,7 +14,7 @@ for d in sorted(glob.glob('gpurun_out/pmcd_${tag}_*/')):
     for f in glob.glob(d + '*counter_collection.csv'):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            for key in ('decode_fixed', 'crc_chunks', 'encode_kernel'):
+            for key in ('decode_fixed', 'crc_mfma', 'crc_chunks', 'encode_kernel'):
                 if key in r['Kernel_Name']: agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
         for key, cs in agg.items():
             for k, v in cs.items(): out.setdefault(key, {})[k] = sum(v) / len(v)
