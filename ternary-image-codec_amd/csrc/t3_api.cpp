@@ -28,7 +28,8 @@ struct Ctx {
     RsTables* d_tab = nullptr;
     uint8_t* d_P[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     std::map<uint32_t, LutImage> luts;                  // key = kmask | mode << 8
-    void* buf[4] = {nullptr, nullptr, nullptr, nullptr}; size_t cap[4] = {0, 0, 0, 0};   // grow-only device scratch
+    void* buf[4] = {nullptr, nullptr, nullptr, nullptr}; size_t cap[4] = {0, 0, 0, 0};   // grow-only device scratch (slots 0, 1: host-buffer entry points)
+    std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> sbuf;              // slots 2, 3: intermediates of the *_dev entry points, one set per caller stream
     uint32_t* d_ctr = nullptr; std::map<hipStream_t, uint32_t> ctr_slot;   // tile-ticket counters, one pair per stream in use
     uint32_t* d_flag = nullptr;                         // failure counter for the synchronous decode entry points
     std::string hip_err;
@@ -42,7 +43,19 @@ int fail_hip(hipError_t e, const char* what) { g.hip_err = std::string(what) + "
 int k_index(int k) { return k == 24 ? 0 : k == 22 ? 1 : k == 20 ? 2 : k == 18 ? 3 : -1; }
 const int kOfIndex[4] = {24, 22, 20, 18};
 
-int scratch(int slot, size_t bytes, void** out) {
+int scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr) {
+    if (slot >= 2) {                                     // per stream: two streams may have frames in flight at the same time
+        auto& e = g.sbuf[std::make_pair(slot, s)];
+        if (bytes > e.second) {
+            if (e.first) HIPCHK(hipFree(e.first));       // synchronises with whatever still reads it
+            e.first = nullptr; e.second = 0;
+            const size_t want = bytes + bytes / 8 + 4096;
+            HIPCHK(hipMalloc(&e.first, want));
+            e.second = want;
+        }
+        *out = e.first;
+        return T3_OK;
+    }
     if (bytes > g.cap[slot]) {
         if (g.buf[slot]) HIPCHK(hipFree(g.buf[slot]));
         g.buf[slot] = nullptr; g.cap[slot] = 0;
@@ -328,7 +341,7 @@ int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, vo
     const uint32_t hs = (uint32_t)header_encode(*cfg, n_raw, hdr);
     const uint32_t pad = (uint32_t)(9 * L.out_words - L.out_syms);
     uint8_t* body_out = (uint8_t*)d_out + hs; uint8_t* frame_out = (uint8_t*)d_out;
-    if (L.beacon_on) { void* p; rc = scratch(2, L.body_syms + 64, &p); if (rc) return rc; body_out = (uint8_t*)p; frame_out = nullptr; }
+    if (L.beacon_on) { void* p; rc = scratch(2, L.body_syms + 64, &p, s); if (rc) return rc; body_out = (uint8_t*)p; frame_out = nullptr; }
     // group bands into launches: all together when the lcm of their k's keeps the tile small, else one launch per k
     uint32_t kmask = 0; for (int b = 0; b < 9; ++b) kmask |= 1u << k_index(L.band_k[b]);
     std::vector<uint32_t> groups;
@@ -421,6 +434,8 @@ int t3hip_shutdown(void) {
     (void)hipDeviceSynchronize();
     for (auto& kv : g.luts) (void)hipFree(kv.second.d_img);
     g.luts.clear();
+    for (auto& kv : g.sbuf) if (kv.second.first) (void)hipFree(kv.second.first);
+    g.sbuf.clear();
     for (int i = 0; i < 4; ++i) { if (g.buf[i]) (void)hipFree(g.buf[i]); g.buf[i] = nullptr; g.cap[i] = 0; for (int m = 0; m < 2; ++m) { (void)hipFree(g.d_P[i][m]); g.d_P[i][m] = nullptr; } }
     (void)hipFree(g.d_tab); (void)hipFree(g.d_flag); (void)hipStreamDestroy(g.stream);
     g.ready = false; g.dev = -1;
@@ -547,7 +562,7 @@ int t3hip_event_destroy(void* ev) { HIPCHK(hipEventDestroy((hipEvent_t)ev)); ret
 namespace t3 {
 int api_ready() { return g.ready ? 1 : 0; }
 hipStream_t api_stream() { return g.stream; }
-int api_scratch(int slot, size_t bytes, void** out) { std::lock_guard<std::mutex> lk(g.mu); return scratch(slot, bytes, out); }
+int api_scratch(int slot, size_t bytes, void** out, hipStream_t s) { std::lock_guard<std::mutex> lk(g.mu); return scratch(slot, bytes, out, s); }
 int api_fail_hip(hipError_t e, const char* what) { return fail_hip(e, what); }
 uint32_t* api_flag() { return g.d_flag; }
 RsTables* api_tables() { return g.d_tab; }

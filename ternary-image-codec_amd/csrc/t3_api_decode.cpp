@@ -15,7 +15,7 @@
 #include "t3_host.hpp"
 
 namespace t3 {
-int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out);
+int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr);
 int api_fail_hip(hipError_t e, const char* what); uint32_t* api_flag(); RsTables* api_tables(); int api_n_cu();
 }  // namespace t3
 using namespace t3;
@@ -174,7 +174,7 @@ int decode_fixed_stream(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_s
     a.in = body; a.in_bytes = body_bytes; a.fail = d_fail; a.tab = d_fxtab;
     for (int b = 0; b < 9; ++b) { a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b]; a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6); }
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
-    void* d_y; int rc = api_scratch(3, L.n_sym + 64, &d_y); if (rc) return rc;
+    void* d_y; int rc = api_scratch(3, L.n_sym + 64, &d_y, s); if (rc) return rc;
     a.ystream = (uint8_t*)d_y;
     int occ = 1; rc = occupancy_of((const void*)decode_stream_kernel, 512, a.lds_bytes, &occ); if (rc) return rc;
     {
@@ -231,7 +231,7 @@ int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_r
             // a beacon is stripped first (its own pass); then the fully fused kernel where it applies, else the two-kernel path
             const uint8_t* body = (const uint8_t*)d_in; uint64_t body_bytes = 9 * n_in; uint32_t hs = L.header_syms;
             if (L.beacon_on) {
-                void* d_b; int brc = api_scratch(2, L.body_syms + 64, &d_b); if (brc) return brc;
+                void* d_b; int brc = api_scratch(2, L.body_syms + 64, &d_b, s); if (brc) return brc;
                 DebeaconArgs d; d.framed = (const uint8_t*)d_in + L.header_syms; d.framed_bytes = 9 * n_in - L.header_syms; d.body = (uint8_t*)d_b; d.body_syms = L.body_syms; d.period = cfg.beacon_words_period; d.slot = cfg.beacon_band_slot;
                 if (L.body_syms) { hipLaunchKernelGGL(debeacon_kernel, dim3(grid_for((L.body_syms + 15) / 16, 256)), dim3(256), 0, s, d); HIPCHK(hipGetLastError()); }
                 body = (const uint8_t*)d_b; body_bytes = L.body_syms; hs = 0;
@@ -246,7 +246,7 @@ int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_r
     const uint64_t units = to_pixels ? 2 * n_words : n_words;
     *n_out = units;
     if (units > cap_units) return T3_E_CAPACITY;
-    void* d_use; int rc = api_scratch(3, use_syms + 64, &d_use); if (rc) return rc;
+    void* d_use; int rc = api_scratch(3, use_syms + 64, &d_use, s); if (rc) return rc;
     a.use = (uint8_t*)d_use;
     if (total) { hipLaunchKernelGGL(dec_gather_rs_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, a); HIPCHK(hipGetLastError()); }
     e.use = (const uint8_t*)d_use; e.use_syms = use_syms; e.out = d_out; e.n_words = n_words; e.to_pixels = to_pixels ? 1 : 0;

@@ -10,7 +10,7 @@
 #include "t3_subword.h"
 
 namespace t3 {
-int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out);
+int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr);
 int api_fail_hip(hipError_t e, const char* what);
 }  // namespace t3
 using namespace t3;
