@@ -728,6 +728,10 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     if constexpr (RSEL > 1) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) Afr[s] = ((const v4i*)a.afrag)[s * 64 + lane];
+        // Let these loads land here, with a wait the compiler's counter tracking sees (the builtin, not inline asm): otherwise it
+        // protects their first use inside the tile loop with s_waitcnt vmcnt(0) in front of the first MFMA of every tile, which also
+        // waits for the next tile's input prefetch and the previous tile's stores.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0) only (gfx9 encoding: vm[3:0] | exp << 4 | lgkm << 8 | vm[5:4] << 14)
     }
 
 #ifdef T3_STAMPS   // diagnostic build: per-phase cycle sums of wave 0 (never in the product build)
@@ -762,11 +766,18 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     uint32_t* const ctr = a.tile_ctr + 64u * cls;                              // one counter per class, 256 B apart
     const uint32_t wgc = (gridDim.x - cls + NC - 1u) / NC;                     // workgroups in this class
     // a class's tiles are cls + NC j: j < wgc first tiles (= blockIdx), wgc <= j < 2 wgc second tiles (static too), then tickets
-    uint32_t pend = 0;                                                         // thread 0: ticket of the tile two after the current one
-    if (dyn && tid == 0) pend = atomicAdd(ctr, 1u);
     // the input of tile i+1 is requested at the top of tile i into the other stage buffer, by the waves that phase 1 (pixels)
     // leaves idle: issuing the LDS-DMA costs ~400 cycles per KiB piece and would otherwise sit between the two phases
     const uint32_t w0 = FE == FE_PIXELS ? min(a.p1_wpp, nwv - 1u) : 0u;
+    // Tickets are drawn by lane 0 of the LAST wave: the compiler turns the atomic into its wave-aggregated form, which reads the
+    // result back at once (s_waitcnt vmcnt(0): the atomic's round trip plus the acknowledgement of the wave's stores of the
+    // previous tile).  On thread 0 that stall sat in front of phase 1's conversion, on the critical path of every tile; the
+    // last wave has no conversion work (pixels), and is taken off prefetch duty so that the wait does not cover a DMA either.
+    const bool drawer = dyn && tid == (nwv - 1u) * 64u;
+    const bool excl = dyn && FE == FE_PIXELS && w0 + 1u < nwv;                 // the drawing wave issues no prefetch
+    const uint32_t n_pf = nwv - w0 - (excl ? 1u : 0u);
+    uint32_t pend = 0;                                                         // drawer: ticket of the tile two after the current one
+    if (drawer) pend = atomicAdd(ctr, 1u);
     uint32_t par = 0;
     for (uint32_t tile = blockIdx.x, nxt = dyn ? cls + NC * (wgc + blockIdx.x / NC) : blockIdx.x + gridDim.x, nn = 0; tile < a.n_tiles; tile = nxt, nxt = nn, par ^= 1u) {
         const uint32_t S0 = tile * TS;
@@ -777,10 +788,10 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             barrier_input(younger);                                           // this tile's input has landed, everyone left phase 2
             T3_STAMP(0);
             uint32_t ticket = 0;
-            if (dyn && tid == 0) ticket = atomicAdd(ctr, 1u);                 // drawn three tiles ahead: its latency hides under a whole tile
+            if (drawer) ticket = atomicAdd(ctr, 1u);                          // drawn three tiles ahead
 #ifndef T3_ABL_NO_PREFETCH
-            if (nxt < a.n_tiles && wave >= w0)
-                stage_input<FE>(a, a.stage_off + (par ^ 1u) * a.stage_stride, first_group(need_lo(nxt * TS)), (need_hi(nxt * TS) + GS - 1u) / GS, lane, wave - w0, nwv - w0);
+            if (nxt < a.n_tiles && wave >= w0 && wave - w0 < n_pf)
+                stage_input<FE>(a, a.stage_off + (par ^ 1u) * a.stage_stride, first_group(need_lo(nxt * TS)), (need_hi(nxt * TS) + GS - 1u) / GS, lane, wave - w0, n_pf);
 #endif
             T3_STAMP(4);
 #ifndef T3_ABL_NO_P1
@@ -789,7 +800,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             else convert_groups<FE, false, SH>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, tid, nthr);
 #endif
             T3_STAMP(5);                                                      // (diagnostic) this wave's conversion
-            if (dyn && tid == 0) { *(uint32_t*)(lds + 328) = cls + NC * (2u * wgc + pend); pend = ticket; }
+            if (drawer) { *(uint32_t*)(lds + 328) = cls + NC * (2u * wgc + pend); pend = ticket; }
             barrier_lds();                                                    // symbols complete
             T3_STAMP(1);
             nn = dyn ? __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + 328)) : nxt + gridDim.x;   // the tile after the next one
@@ -884,7 +895,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 #endif
         T3_STAMP(2);
     }
-    if (dyn && tid == 0) {
+    if (drawer) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this workgroup's last ticket draw has completed
         if (atomicAdd(a.tile_ctr + 64u * NC, 1u) == gridDim.x - 1u) {          // ... and so has everyone else's: re-arm for the next launch
             for (uint32_t c = 0; c <= NC; ++c) __hip_atomic_store(a.tile_ctr + 64u * c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
