@@ -36,7 +36,7 @@ int t3hip_subword_extract_dev(const void* d_words, uint64_t n_words, int N, uint
     const uint64_t chunk = (0xF0000000ull / (uint64_t)N) & ~3ull;
     for (uint64_t w0 = 0; w0 < n_words; w0 += chunk) {
         const uint64_t nw = std::min(chunk, n_words - w0);
-        hipLaunchKernelGGL(subword_extract_kernel, dim3(blocks_for((nw * (uint64_t)N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(subword_extract_kernel, dim3((unsigned)std::min<uint64_t>((nw + 511) / 512, 256u * 8u)), dim3(256), 0, (hipStream_t)stream,
                            (const uint8_t*)d_words + 9 * w0, nw, N, d_trits + w0 * (uint64_t)N);
         HIPCHK(hipGetLastError());
     }
@@ -50,7 +50,7 @@ int t3hip_subword_build_dev(const uint8_t* d_trits, uint64_t n_trits, int N, uin
     if (*n_words > cap_words) return T3_E_CAPACITY;
     if (!*n_words) return T3_OK;
     if (!d_trits || !d_words) return T3_E_ARG;
-    hipLaunchKernelGGL(subword_build_kernel, dim3(blocks_for(*n_words)), dim3(256), 0, (hipStream_t)stream, d_trits, n_trits, N, (uint32_t)fill, (uint8_t*)d_words, *n_words);
+    hipLaunchKernelGGL(subword_build_kernel, dim3((unsigned)std::min<uint64_t>((*n_words + 511) / 512, 256u * 8u)), dim3(256), 0, (hipStream_t)stream, d_trits, n_trits, N, (uint32_t)fill, (uint8_t*)d_words, *n_words);
     HIPCHK(hipGetLastError()); return T3_OK;
 }
 
@@ -60,7 +60,7 @@ int t3hip_base243_pack_dev(const uint8_t* d_trits, uint64_t n_trits, uint8_t* d_
     *n_bytes = t3hip_base243_bytes(n_trits);
     if (*n_bytes > cap_bytes) return T3_E_CAPACITY;
     if (!d_out || (n_trits && !d_trits)) return T3_E_ARG;
-    hipLaunchKernelGGL(base243_pack_kernel, dim3(blocks_for((n_trits + 4) / 5)), dim3(256), 0, (hipStream_t)stream, d_trits, n_trits, d_out);
+    hipLaunchKernelGGL(base243_pack_kernel, dim3(blocks_for(((n_trits + 4) / 5 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_trits, n_trits, d_out);
     HIPCHK(hipGetLastError()); return T3_OK;
 }
 
@@ -71,7 +71,7 @@ int t3hip_base243_unpack_dev(const uint8_t* d_in, uint64_t n_bytes, uint64_t tot
     if (total > 5 * (n_bytes - 4)) return T3_E_HEADER;                     // TPACK:49: fewer trits than announced -> false
     if (!total) return T3_OK;
     if (!d_in || !d_trits) return T3_E_ARG;
-    hipLaunchKernelGGL(base243_unpack_kernel, dim3(blocks_for(n_bytes - 4)), dim3(256), 0, (hipStream_t)stream, d_in + 4, n_bytes - 4, total, d_trits);
+    hipLaunchKernelGGL(base243_unpack_kernel, dim3(blocks_for((n_bytes - 4 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_in + 4, n_bytes - 4, total, d_trits);
     HIPCHK(hipGetLastError()); return T3_OK;
 }
 

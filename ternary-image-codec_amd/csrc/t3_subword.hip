@@ -19,60 +19,153 @@ __device__ __forceinline__ uint32_t d3(uint32_t x) { return (x * 171u) >> 9; }  
 __device__ __forceinline__ uint32_t m27(uint32_t x) { return x - 27u * ((x * 2428u) >> 16); }   // x < 256: unpack3 reduces the digit (OLD:28-31)
 }  // namespace
 
-// One lane = one output dword = 4 consecutive trits of the stream; trit g is trit g % N of word g / N.  The symbol bytes
-// it needs (each read by up to three trits) come through the vector L1; the stores are fully coalesced.  A launch
-// covers < 2^32 trits (the launcher splits longer streams) so that one 32-bit division per lane locates the first trit.
+// A workgroup step takes 512 words (4608 bytes, 16-byte aligned in the stream): every lane expands dwords of four symbols
+// into twelve trit bytes in LDS (27 bytes per word), then the N leading trits of each word leave as whole 16-byte stores
+// (N * 512 is a multiple of 16): straight from the image when N = 27, gathered byte-wise otherwise.  Loads and stores are
+// coalesced; the first version (one lane = four output trits read through the vector L1) reached 1.2 TB/s.
 __global__ __launch_bounds__(256) void subword_extract_kernel(const uint8_t* __restrict__ words, uint64_t n_words, int N, uint8_t* __restrict__ out) {
-    const uint32_t n_trits = (uint32_t)(n_words * (uint64_t)N);
-    const uint32_t g0 = 4u * (blockIdx.x * blockDim.x + threadIdx.x);
-    if (g0 >= n_trits) return;
-    uint32_t w = g0 / (uint32_t)N, i = g0 - w * (uint32_t)N;
-    uint32_t v = 0;
+    __shared__ __attribute__((aligned(16))) uint8_t img[27 * 512 + 16];
+    const uint32_t tid = threadIdx.x, uN = (uint32_t)N;
+    const uint64_t n_steps = (n_words + 511) / 512;
+    const bool fast_io = (((uintptr_t)words | (uintptr_t)out) & 15u) == 0;
+    for (uint64_t step = blockIdx.x; step < n_steps; step += gridDim.x) {
+        const uint64_t w0 = step * 512;
+        const uint32_t nw = (uint32_t)min((uint64_t)512, n_words - w0);
+        const uint8_t* src = words + 9 * w0;
+        for (uint32_t q = tid; 4u * q < 9u * nw; q += 256u) {                  // dword q = symbols 4q .. 4q+3 of the step
+            uint32_t v;
+            if (fast_io && 4u * q + 4u <= 9u * nw) v = *(const uint32_t*)(src + 4u * q);
+            else { v = 0; for (uint32_t i = 0; i < 4u && 4u * q + i < 9u * nw; ++i) v |= (uint32_t)src[4u * q + i] << (8u * i); }
+            uint32_t o[3] = {0, 0, 0};
 #pragma unroll
-    for (uint32_t q = 0; q < 4; ++q) {
-        if (g0 + q < n_trits) {
-            const uint32_t s3 = d3(i), r = i - 3u * s3;                       // symbol index, digit index
-            const uint32_t sy = m27(words[(uint64_t)w * 9u + s3]);
-            const uint32_t q1 = d3(sy), q2 = d3(q1);
-            const uint32_t d = r == 0 ? sy - 3u * q1 : (r == 1 ? q1 - 3u * q2 : q2);
-            v |= d << (8u * q);
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t sy = m27((v >> (8u * i)) & 0xFFu), q1 = d3(sy), q2 = d3(q1);
+                const uint32_t t3 = (sy - 3u * q1) | (q1 - 3u * q2) << 8 | q2 << 16;   // three trit bytes
+                const uint32_t bit = 24u * i;                                            // position in the 96-bit group
+                o[bit >> 5] |= t3 << (bit & 31u);
+                if ((bit & 31u) > 8u) o[(bit >> 5) + 1u] |= t3 >> (32u - (bit & 31u));
+            }
+            *(uint32_t*)(img + 12u * q) = o[0]; *(uint32_t*)(img + 12u * q + 4u) = o[1]; *(uint32_t*)(img + 12u * q + 8u) = o[2];
         }
-        if (++i == (uint32_t)N) { i = 0; ++w; }
+        __syncthreads();
+        const uint32_t n_out = uN * nw;                                         // trits this step produces
+        uint8_t* dst = out + (uint64_t)uN * w0;
+        for (uint32_t u = tid; 16u * u < n_out; u += 256u) {
+            const uint32_t t0 = 16u * u;
+            uint32_t r[4];
+            if (uN == 27u) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[k] = *(const uint32_t*)(img + t0 + 4u * k);
+            } else {
+                uint32_t w = t0 / uN, i = t0 - w * uN;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t x = 0;
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b) { x |= (uint32_t)img[27u * w + i] << (8u * b); if (++i == uN) { i = 0; ++w; } }
+                    r[k] = x;
+                }
+            }
+            if (fast_io && t0 + 16u <= n_out) *(uint4*)(dst + t0) = make_uint4(r[0], r[1], r[2], r[3]);
+            else for (uint32_t b = 0; b < 16u && t0 + b < n_out; ++b) dst[t0 + b] = (uint8_t)(r[b >> 2] >> (8u * (b & 3u)));
+        }
+        __syncthreads();
     }
-    if (g0 + 4u <= n_trits) *(uint32_t*)(out + g0) = v;
-    else for (uint32_t q = 0; g0 + q < n_trits; ++q) out[g0 + q] = (uint8_t)(v >> (8u * q));
 }
 
-// One lane = one word: N trits of the stream (fewer for the last word: the rest of its first N slots is zero), slots N..26 = fill.
+// Inverse of the extraction, same staging: a workgroup step builds 512 words.  Their N * 512 trits (a multiple of 16 bytes)
+// enter LDS with 16-byte loads; one lane then packs one output dword = four symbols (slots >= N of a word = fill, a slot past
+// the end of the stream = 0: the last word is zero-padded, OLD:845-859) and stores it.  First version: one lane = one word,
+// 27 byte loads and 9 byte stores, 1.9 TB/s.
 __global__ __launch_bounds__(256) void subword_build_kernel(const uint8_t* __restrict__ trits, uint64_t n_trits, int N, uint32_t fill, uint8_t* __restrict__ words, uint64_t n_words) {
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words) return;
-    const uint64_t base = w * (uint64_t)N;
-    uint32_t t[27];
+    __shared__ __attribute__((aligned(16))) uint8_t lin[27 * 512 + 16];
+    const uint32_t tid = threadIdx.x, uN = (uint32_t)N;
+    const uint64_t n_steps = (n_words + 511) / 512;
+    const bool fast_io = (((uintptr_t)trits | (uintptr_t)words) & 15u) == 0;
+    for (uint64_t step = blockIdx.x; step < n_steps; step += gridDim.x) {
+        const uint64_t w0 = step * 512, t0 = w0 * uN;
+        const uint32_t nw = (uint32_t)min((uint64_t)512, n_words - w0);
+        const uint32_t n_in = (uint32_t)min((uint64_t)uN * nw, n_trits - t0);    // trits of the stream that belong to this step
+        for (uint32_t u = tid; 16u * u < n_in; u += 256u) {
+            if (fast_io && 16u * u + 16u <= n_in) *(uint4*)(lin + 16u * u) = *(const uint4*)(trits + t0 + 16u * u);
+            else for (uint32_t b = 0; b < 16u && 16u * u + b < n_in; ++b) lin[16u * u + b] = trits[t0 + 16u * u + b];
+        }
+        __syncthreads();
+        uint8_t* dst = words + 9 * w0;
+        for (uint32_t q = tid; 4u * q < 9u * nw; q += 256u) {                  // output dword q = symbols 4q .. 4q+3 of the step
+            uint32_t s = 4u * q, w = (s * 7282u) >> 16, k = s - 9u * w;        // s / 9 for s < 4608
+            uint32_t v = 0;
 #pragma unroll
-    for (int i = 0; i < 27; ++i) t[i] = i < N ? (base + i < n_trits ? trits[base + i] : 0u) : fill;
+            for (uint32_t e = 0; e < 4; ++e) {
+                uint32_t sym = 0, p = 1;
 #pragma unroll
-    for (int s = 0; s < 9; ++s) words[w * 9 + s] = (uint8_t)(t[3 * s] + 3u * t[3 * s + 1] + 9u * t[3 * s + 2]);   // pack3 OLD:24-27 (no reduction)
+                for (uint32_t d = 0; d < 3; ++d) {
+                    const uint32_t i = 3u * k + d, g = w * uN + i;
+                    const uint32_t t = i < uN ? (g < n_in ? (uint32_t)lin[g] : 0u) : fill;
+                    sym += p * t; p *= 3u;
+                }
+                v |= (sym & 0xFFu) << (8u * e);                               // pack3 OLD:24-27 (no reduction)
+                if (++k == 9u) { k = 0; ++w; }
+            }
+            if (fast_io && 4u * q + 4u <= 9u * nw) *(uint32_t*)(dst + 4u * q) = v;
+            else for (uint32_t e = 0; e < 4u && 4u * q + e < 9u * nw; ++e) dst[4u * q + e] = (uint8_t)(v >> (8u * e));
+        }
+        __syncthreads();
+    }
 }
 
-// One lane = one output byte = 5 trits; lane 0 also writes the 4-byte count header.
+// One lane = four output bytes = 20 trits = five aligned dwords of the stream; lane 0 also writes the 4-byte count header.
 __global__ __launch_bounds__(256) void base243_pack_kernel(const uint8_t* __restrict__ trits, uint64_t n_trits, uint8_t* __restrict__ out) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j == 0) { const uint32_t total = (uint32_t)n_trits; out[0] = (uint8_t)total; out[1] = (uint8_t)(total >> 8); out[2] = (uint8_t)(total >> 16); out[3] = (uint8_t)(total >> 24); }
-    if (5 * j >= n_trits) return;
-    uint32_t v = 0, p = 1;
+    const uint64_t t0 = 20 * j;
+    if (t0 >= n_trits) return;
+    const uint64_t n_bytes = (n_trits + 4) / 5;
+    if (t0 + 20 <= n_trits && (((uintptr_t)trits | (uintptr_t)out) & 3u) == 0) {
+        const uint32_t* p = (const uint32_t*)(trits + t0);
+        uint32_t w[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { v += p * (5 * j + q < n_trits ? trits[5 * j + q] : 0u); p *= 3u; }
-    out[4 + j] = (uint8_t)v;
+        for (int i = 0; i < 5; ++i) w[i] = p[i];
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+            uint32_t x = 0, pw = 1;
+#pragma unroll
+            for (uint32_t q = 0; q < 5; ++q) { const uint32_t b = 5u * e + q; x += pw * ((w[b >> 2] >> (8u * (b & 3u))) & 0xFFu); pw *= 3u; }
+            v |= (x & 0xFFu) << (8u * e);
+        }
+        *(uint32_t*)(out + 4 + 4 * j) = v;
+    } else {
+        for (uint64_t e = 4 * j; e < min(4 * j + 4, n_bytes); ++e) {
+            uint32_t x = 0, pw = 1;
+            for (int q = 0; q < 5; ++q) { x += pw * (5 * e + q < n_trits ? trits[5 * e + q] : 0u); pw *= 3u; }
+            out[4 + e] = (uint8_t)x;
+        }
+    }
 }
 
-// One lane = one input byte -> up to 5 trits (only the first `total` trits exist)
+// One lane = four input bytes -> up to 20 trits = five aligned dwords (only the first `total` trits exist)
 __global__ __launch_bounds__(256) void base243_unpack_kernel(const uint8_t* __restrict__ in, uint64_t n_bytes, uint64_t total, uint8_t* __restrict__ trits) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_bytes || 5 * j >= total) return;
-    uint32_t v = in[j];
+    if (4 * j >= n_bytes || 20 * j >= total) return;
+    if (4 * j + 4 <= n_bytes && 20 * j + 20 <= total && (((uintptr_t)in | (uintptr_t)trits) & 3u) == 0) {
+        const uint32_t v4 = *(const uint32_t*)(in + 4 * j);
+        uint32_t w[5] = {0, 0, 0, 0, 0};
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { const uint32_t d = v / 3u; if (5 * j + q < total) trits[5 * j + q] = (uint8_t)(v - 3u * d); v = d; }
+        for (uint32_t e = 0; e < 4; ++e) {
+            uint32_t v = (v4 >> (8u * e)) & 0xFFu;
+#pragma unroll
+            for (uint32_t q = 0; q < 5; ++q) { const uint32_t d = d3(v), b = 5u * e + q; w[b >> 2] |= (v - 3u * d) << (8u * (b & 3u)); v = d; }
+        }
+        uint32_t* p = (uint32_t*)(trits + 20 * j);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) p[i] = w[i];
+    } else {
+        for (uint64_t e = 4 * j; e < min(4 * j + 4, n_bytes); ++e) {
+            uint32_t v = in[e];
+            for (int q = 0; q < 5; ++q) { const uint32_t d = v / 3u; if (5 * e + q < total) trits[5 * e + q] = (uint8_t)(v - 3u * d); v = d; }
+        }
+    }
 }
 
 // out[i] = in[i] % 27, 16 bytes per lane where possible
