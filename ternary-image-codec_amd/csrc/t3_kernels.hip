@@ -484,6 +484,7 @@ __device__ __forceinline__ void convert_groups(const EncArgs& a, uint32_t stage,
     constexpr uint32_t EM = FE == FE_PIXELS ? 2u : 4u;                     // bytes per LDS store on the fast path (26 g is 2-aligned)
     const uint64_t b0 = ((uint64_t)g_base * GB) & ~15ull;
     for (uint32_t g0 = g_lo; g0 < g_hi; g0 += nthr) {                      // wave-uniform trip count (ballots inside)
+        if (g0 + (tid & ~63u) >= g_hi) break;                                // a wave without a live lane has nothing to convert (the ballots are per wave)
         const uint32_t g = g0 + tid; const bool live = g < g_hi;
         const uint32_t src = stage + (uint32_t)((uint64_t)(live ? g : g_lo) * GB - b0);
         const uint32_t u0 = g * GS;
@@ -508,8 +509,12 @@ __device__ __forceinline__ void convert_groups(const EncArgs& a, uint32_t stage,
                 px3_to_sym13(c, sq);
             } else {
                 uint32_t c[27]; bool bad = false;
+                // the half group's 27 bytes as 14 halfwords (groups are 2-byte aligned; q = 1 starts on an odd byte)
+                uint32_t hb[28];
 #pragma unroll
-                for (uint32_t i = 0; i < 27; ++i) { c[i] = lds[src + 27u * q + i]; bad |= c[i] >= 27u; }
+                for (uint32_t i = 0; i < 14; ++i) { const uint32_t h = *(const uint16_t*)(lds + src + 26u * q + 2u * i); hb[2 * i] = h & 0xFFu; hb[2 * i + 1] = h >> 8; }
+#pragma unroll
+                for (uint32_t i = 0; i < 27; ++i) { c[i] = hb[q + i]; bad |= c[i] >= 27u; }
                 if (__builtin_amdgcn_ballot_w64(bad) != 0) {
 #pragma unroll
                     for (uint32_t i = 0; i < 27; ++i) c[i] = mod27(c[i]);
@@ -768,13 +773,13 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     // a class's tiles are cls + NC j: j < wgc first tiles (= blockIdx), wgc <= j < 2 wgc second tiles (static too), then tickets
     // the input of tile i+1 is requested at the top of tile i into the other stage buffer, by the waves that phase 1 (pixels)
     // leaves idle: issuing the LDS-DMA costs ~400 cycles per KiB piece and would otherwise sit between the two phases
-    const uint32_t w0 = FE == FE_PIXELS ? min(a.p1_wpp, nwv - 1u) : 0u;
+    const uint32_t w0 = FE == FE_PIXELS ? min(a.p1_wpp, nwv - 1u) : min((TS / GS + 2u + 63u) / 64u, nwv - 1u);   // raw words: waves that hold a lane group of the tile
     // Tickets are drawn by lane 0 of the LAST wave: the compiler turns the atomic into its wave-aggregated form, which reads the
     // result back at once (s_waitcnt vmcnt(0): the atomic's round trip plus the acknowledgement of the wave's stores of the
     // previous tile).  On thread 0 that stall sat in front of phase 1's conversion, on the critical path of every tile; the
     // last wave has no conversion work (pixels), and is taken off prefetch duty so that the wait does not cover a DMA either.
     const bool drawer = dyn && tid == (nwv - 1u) * 64u;
-    const bool excl = dyn && FE == FE_PIXELS && w0 + 1u < nwv;                 // the drawing wave issues no prefetch
+    const bool excl = dyn && w0 + 1u < nwv;                                    // the drawing wave issues no prefetch
     const uint32_t n_pf = nwv - w0 - (excl ? 1u : 0u);
     uint32_t pend = 0;                                                         // drawer: ticket of the tile two after the current one
     if (drawer) pend = atomicAdd(ctr, 1u);
