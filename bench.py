@@ -87,9 +87,17 @@ def main():
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    # T3_BENCH_REHEARSE_ONE_GPU=1: dry run of the N>1 control flow on a single card (every rank on cuda:0, collectives over
+    # gloo with CPU tensors); the numbers it prints mean nothing, the point is that the multi-rank path is exercised end to end
+    rehearse = world > 1 and os.environ.get("T3_BENCH_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     t3 = ge.load_package()
     sf = __import__("ternary_image_codec_amd.superframe", fromlist=["x"])
     t3.init(local)
@@ -164,7 +172,7 @@ def main():
     if s2 is not None:
         cur.wait_stream(s2)
     if world > 1 and not args.encode_only:
-        gathered = sf.gather_records(d_recs)               # the one exchange step: super-frame index records (RCCL all-gather)
+        gathered = sf.gather_records(d_recs.cpu() if rehearse else d_recs)   # the one exchange step: super-frame index records (RCCL all-gather)
     torch.cuda.synchronize()
     if not args.encode_only and not args.sync_decode:      # the streaming entry's verdicts: header as expected, no uncorrectable block
         verdicts = d_verdict[: args.steps].cpu().numpy()
@@ -173,7 +181,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -59,3 +59,18 @@ def test_dropin_caller_sequence(gpu, orc, tmp_path):
     f0 = np.ascontiguousarray(enc).view(np.uint8).reshape(-1); f2 = np.ascontiguousarray(encf).view(np.uint8).reshape(-1)
     want = expect_t3v(27, 256, 256, [f0, np.zeros(0, np.uint8), f2], b'{"codec":"v6"}', [b'{"f":0}', b"", b'{"f":2}'])
     assert out["t3v_bytes"] == len(want) and out["t3v_hash"] == ol.fnv_hex(np.frombuffer(want, np.uint8))
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal(gpu):
+    """bench.py's N>1 control flow (rank-sharded frames, one all-gather of index records, max-over-ranks timing, the index
+    assertions) on one card: two ranks on cuda:0, collectives over gloo (T3_BENCH_REHEARSE_ONE_GPU=1).  The driver runs the
+    real thing over RCCL on a whole node; this keeps that path from rotting."""
+    import sys
+    env = dict(os.environ, T3_BENCH_REHEARSE_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak" and line["value"] > 0 and "cpu_baseline" not in line
