@@ -249,6 +249,14 @@ int t3hip_rgb_to_quant(const uint8_t* rgb, uint64_t n_px, void* px6);
 int t3hip_quant_to_rgb(const void* px6, uint64_t n_px, uint8_t* rgb);
 int t3hip_rgb_to_quant_dev(const uint8_t* d_rgb, uint64_t n_px, void* d_px6, void* stream);
 int t3hip_quant_to_rgb_dev(const void* d_px6, uint64_t n_px, uint8_t* d_rgb, void* stream);
+/* RGB frame -> coded stream and back in one call each (what a caller of io_image.hpp's rgb_to_quant_stream +
+ * encode_raw_pixels_to_words + encode_profile_from_raw does, old/src/main.cpp:12-19): the bridge kernel into a per-stream
+ * scratch, then the fused encode / after the decode.  Both asynchronous on `stream`; the decode uses the streaming entry
+ * (known configuration, d_verdict as for t3hip_decode_frame_async).  n_px pixels -> (n_px + 1) / 2 raw words. */
+int t3hip_encode_rgb_dev(const uint8_t* d_rgb, uint64_t n_px, const t3_cfg* cfg, void* d_out9, uint64_t cap_words,
+                         uint64_t* n_out, void* stream);
+int t3hip_decode_rgb_async(const void* d_in9, uint64_t n_in, const t3_cfg* cfg, uint64_t n_px, uint8_t* d_rgb,
+                           uint32_t* d_verdict, void* stream);
 
 /* ---- timing helper: HIP events on the caller's stream -------------------------------- */
 int t3hip_event_create(void** ev);

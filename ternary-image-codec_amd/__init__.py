@@ -347,6 +347,18 @@ def quant_to_rgb_dev(d_px, n_px, d_rgb, stream=0):
     _chk(lib().t3hip_quant_to_rgb_dev(C.c_void_p(d_px), C.c_uint64(n_px), C.c_void_p(d_rgb), C.c_void_p(stream)), "t3hip_quant_to_rgb_dev")
 
 
+def encode_rgb_dev(d_rgb, n_px, cfg, d_out, cap_words, stream=0):
+    """RGB8 frame (device) -> coded stream: bridge kernel + fused encode on `stream`; returns the coded word count."""
+    n = C.c_uint64()
+    _chk(lib().t3hip_encode_rgb_dev(C.c_void_p(d_rgb), C.c_uint64(n_px), C.byref(cfg), C.c_void_p(d_out), C.c_uint64(cap_words), C.byref(n), C.c_void_p(stream)), "t3hip_encode_rgb_dev")
+    return n.value
+
+
+def decode_rgb_async(d_in, n_in, cfg, n_px, d_rgb, d_verdict, stream=0):
+    """Coded stream -> RGB8 frame with the stream's known configuration (streaming decode entry + bridge kernel)."""
+    _chk(lib().t3hip_decode_rgb_async(C.c_void_p(d_in), C.c_uint64(n_in), C.byref(cfg), C.c_uint64(n_px), C.c_void_p(d_rgb), C.c_void_p(d_verdict), C.c_void_p(stream)), "t3hip_decode_rgb_async")
+
+
 def subword_extract_dev(d_words, n_words, N, d_trits, stream=0):
     _chk(lib().t3hip_subword_extract_dev(C.c_void_p(d_words), C.c_uint64(n_words), C.c_int(int(N)), C.c_void_p(d_trits), C.c_void_p(stream)), "t3hip_subword_extract_dev")
 

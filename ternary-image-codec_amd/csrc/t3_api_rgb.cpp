@@ -54,6 +54,23 @@ int t3hip_quant_to_rgb_dev(const void* d_px6, uint64_t n_px, uint8_t* d_rgb, voi
     hipLaunchKernelGGL(quant_to_rgb_kernel, dim3(blocks_for((n_px + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)d_px6, n_px, d_rgb, t);
     HIPCHK(hipGetLastError()); return T3_OK;
 }
+// slot 4 of the stream's scratch set holds the quantised pixels between the two launches (slots 2 and 3 belong to the codec)
+int t3hip_encode_rgb_dev(const uint8_t* d_rgb, uint64_t n_px, const t3_cfg* cfg, void* d_out, uint64_t cap_words, uint64_t* n_out, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!cfg || !n_out || (n_px && !d_rgb)) return T3_E_ARG;
+    void* d_q; int rc = api_scratch(4, 6 * n_px + 64, &d_q, (hipStream_t)stream); if (rc) return rc;
+    rc = t3hip_rgb_to_quant_dev(d_rgb, n_px, d_q, stream); if (rc) return rc;
+    return t3hip_encode_frame_dev(d_q, n_px, cfg, d_out, cap_words, n_out, stream);
+}
+int t3hip_decode_rgb_async(const void* d_in, uint64_t n_in, const t3_cfg* cfg, uint64_t n_px, uint8_t* d_rgb, uint32_t* d_verdict, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!cfg || !d_verdict || (n_px && !d_rgb)) return T3_E_ARG;
+    const uint64_t n_raw = (n_px + 1) / 2;
+    void* d_q; int rc = api_scratch(4, 12 * n_raw + 64, &d_q, (hipStream_t)stream); if (rc) return rc;
+    uint64_t n_units = 0;
+    rc = t3hip_decode_frame_async(d_in, n_in, cfg, n_raw, d_q, 2 * n_raw, &n_units, 1, d_verdict, stream); if (rc) return rc;
+    return t3hip_quant_to_rgb_dev(d_q, n_px, d_rgb, stream);
+}
 int t3hip_rgb_to_quant(const uint8_t* rgb, uint64_t n_px, void* px6) {
     if (!api_ready()) return T3_E_NODEVICE;
     if (!n_px) return T3_OK;

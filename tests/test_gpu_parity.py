@@ -470,3 +470,29 @@ def test_decode_frame_async_streaming(gpu, orc, name):
     if not L.beacon_on and min(L.band_k) >= 20:
         okd, _ = gpu.decode_frame(dead.reshape(-1, 9), gpu.DecoderContext(mode=1))
         v = run(dead)[1]; assert v[0] == 0 and (v[1] >= 1) == (not okd)
+
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npx", [1, 7, 4096, 100_003])
+def test_rgb_frame_encode_decode(t3, orc, gpu, npx):
+    """Row f1 end to end on the device: RGB8 -> bridge -> fused encode equals the oracle's bridge + encode; the streaming
+    decode + inverse bridge gives back what the oracle's quantisation round trip gives (parity of the bridge itself: unpinned)."""
+    import torch
+    rng = np.random.default_rng(npx)
+    rgb = rng.integers(0, 256, size=3 * npx, dtype=np.uint8)
+    cfg, ocfg = both(gpu, dict(profile=2, uep=2), mode=1)
+    q = orc.rgb_to_quant(rgb)
+    rc, want = orc.encode_frame(q, ocfg, cap=npx + 64); assert rc == 0
+    s = torch.cuda.current_stream().cuda_stream
+    d_rgb = torch.from_numpy(rgb).cuda()
+    n_cap = t3.encoded_words((npx + 1) // 2, cfg)
+    d_out = torch.zeros(n_cap * 9 + 64, dtype=torch.uint8, device="cuda")
+    n = t3.encode_rgb_dev(d_rgb.data_ptr(), npx, cfg, d_out.data_ptr(), n_cap, s)
+    torch.cuda.synchronize()
+    assert n == len(want) and np.array_equal(d_out[: 9 * n].cpu().numpy(), np.asarray(want).reshape(-1))
+    d_back = torch.zeros(3 * npx + 64, dtype=torch.uint8, device="cuda"); ver = torch.full((2,), 9, dtype=torch.int32, device="cuda")
+    t3.decode_rgb_async(d_out.data_ptr(), n, cfg, npx, d_back.data_ptr(), ver.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert ver.cpu().numpy().tolist() == [0, 0]
+    assert np.array_equal(d_back[: 3 * npx].cpu().numpy(), np.asarray(orc.quant_to_rgb(q)).reshape(-1))
