@@ -235,7 +235,7 @@ def test_fixed_mode_roundtrip_with_errors(gpu, orc, name):
     exact recovery; and the HIP FIXED path equals the oracle's restatement of the same spec."""
     rng = np.random.default_rng(zlib.crc32(name.encode()) + 13)
     cfg, ocfg = both(gpu, CFGS[name], mode=1)
-    for n in (1, 2, 64, 541, 4321, 100003):
+    for n in (0, 1, 2, 64, 541, 4321, 100003):
         px = rand_pixels(rng, n)
         ok, enc = gpu.encode_frame(px, cfg)
         rc, want = orc.encode_frame(px, ocfg, cap=n + 64)
@@ -343,6 +343,39 @@ def test_subword_dev_entry_points_full_frame(t3, orc, gpu):
     assert torch.equal(back[:, :8], w[:, :8]) and torch.equal(back[:, 8], torch.zeros_like(back[:, 8]))   # trits 24..26 dropped
     sample = slice(12345, 12345 + 4096)
     assert np.array_equal(tr[sample.start * N: sample.stop * N].cpu().numpy(), orc.extract_subword_stream(w[sample].cpu().numpy(), N))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("off", [1, 2, 6])
+def test_subword_dev_entry_points_unaligned(t3, orc, gpu, off):
+    """Device buffers that are not 16-byte aligned take the byte-wise load/store branches of the staged kernels."""
+    import torch
+    rng = np.random.default_rng(off)
+    s = torch.cuda.current_stream().cuda_stream
+    for N, n_words in ((27, 1500), (24, 513), (15, 77)):
+        w = rng.integers(0, 27, (n_words, 9), dtype=np.uint8)
+        want = orc.extract_subword_stream(w, N)
+        d_w = torch.zeros(9 * n_words + 64, dtype=torch.uint8, device="cuda"); d_w[off: off + 9 * n_words] = torch.from_numpy(w.reshape(-1)).cuda()
+        d_t = torch.zeros(N * n_words + 64, dtype=torch.uint8, device="cuda")
+        t3.subword_extract_dev(d_w.data_ptr() + off, n_words, N, d_t.data_ptr() + off, s)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_t[off: off + N * n_words].cpu().numpy(), want)
+        assert int(d_t[:off].max()) == 0 and int(d_t[off + N * n_words:].max()) == 0          # nothing written outside
+        d_b = torch.zeros(9 * n_words + 64, dtype=torch.uint8, device="cuda")
+        assert t3.subword_build_dev(d_t.data_ptr() + off, N * n_words - 5, N, 1, d_b.data_ptr() + off, n_words, s) == n_words
+        torch.cuda.synchronize()
+        assert np.array_equal(d_b[off: off + 9 * n_words].cpu().numpy(), np.asarray(orc.build_words_from_subword_stream(want[:-5], N, 1)).reshape(-1))
+        assert int(d_b[:off].max()) == 0 and int(d_b[off + 9 * n_words:].max()) == 0
+        n_tr = N * n_words - 3
+        d_p = torch.zeros(n_tr // 5 + 80, dtype=torch.uint8, device="cuda")
+        nb = t3.base243_pack_dev(d_t.data_ptr() + off, n_tr, d_p.data_ptr() + off, n_tr // 5 + 16, s)
+        torch.cuda.synchronize()
+        wantp = orc.ut_to_base243(want[:n_tr])
+        assert nb == len(wantp) and np.array_equal(d_p[off: off + nb].cpu().numpy(), wantp)
+        d_u = torch.zeros(n_tr + 64, dtype=torch.uint8, device="cuda")
+        t3.base243_unpack_dev(d_p.data_ptr() + off, nb, n_tr, d_u.data_ptr() + off, s)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_u[off: off + n_tr].cpu().numpy(), want[:n_tr]) and int(d_u[off + n_tr:].max()) == 0
 
 
 # ---- SURVEY 8 row f1: RGB8 <-> quantised YCbCr bridge (parity against the oracle's restatement; the reference header
