@@ -812,15 +812,29 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             if constexpr (IL) {
                 // permutation pass: post-interleave position v of the tile <- pre-interleave symbol il_perm(v) (an involution);
                 // one lane = 4 consecutive positions = one dword of the image phase 2 reads
+                // Rows of the chunk grid map onto themselves, and with rows that are multiples of 4 symbols (tile edges and chunk sizes
+                // are too) an aligned dword of a row stays an aligned dword: copied in even rows, byte-reversed from the mirrored
+                // column in odd rows.  Anything else (other widths, the stream's last short row, the padding past the stream's
+                // end) walks the cursor symbol by symbol.
+                const bool rows4 = (a.il_w & 3u) == 0u && ((a.il_A & 3u) == 0u || a.il_A >= a.n_sym) && (S0 & 3u) == 0u;
                 for (uint32_t g = tid; 4u * g < TS; g += nthr) {
                     uint32_t v = S0 + 4u * g, w4 = 0;
-                    IlCursor cur;
-                    if (v < a.n_sym) cur.init(v, a);
+                    bool done = false;
+                    if (rows4 && v + 4u <= a.n_sym) {
+                        const uint32_t chunk = fdiv(v, a.div_A), base = chunk * a.il_A, rem = v - base, take = min(a.il_A, a.n_sym - base);
+                        const uint32_t r = fdiv(rem, a.div_w), rw = r * a.il_w, c = rem - rw, rowlen = min(a.il_w, take - rw);
+                        if (!(r & 1u)) { w4 = lds_u32(a.sym_off + (v - u_lo)); done = true; }
+                        else if (rowlen == a.il_w) { w4 = __builtin_bswap32(lds_u32(a.sym_off + (base + rw + (a.il_w - 4u - c) - u_lo))); done = true; }
+                    }
+                    if (!done) {
+                        IlCursor cur;
+                        if (v < a.n_sym) cur.init(v, a);
 #pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q, ++v) {
-                        uint32_t u = v;
-                        if (v < a.n_sym) { u = cur.get(); cur.next(a); }
-                        w4 |= lds_u8(a.sym_off + (u - u_lo)) << (8u * q);
+                        for (uint32_t q = 0; q < 4; ++q, ++v) {
+                            uint32_t u = v;
+                            if (v < a.n_sym) { u = cur.get(); cur.next(a); }
+                            w4 |= lds_u8(a.sym_off + (u - u_lo)) << (8u * q);
+                        }
                     }
                     *T3_LDS_WPTR(uint32_t, stage + 4u * g) = w4;
                 }
