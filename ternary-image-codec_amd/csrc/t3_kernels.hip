@@ -817,8 +817,9 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
                 // column in odd rows.  Anything else (other widths, the stream's last short row, the padding past the stream's
                 // end) walks the cursor symbol by symbol.
                 const bool rows4 = (a.il_w & 3u) == 0u && ((a.il_A & 3u) == 0u || a.il_A >= a.n_sym) && (S0 & 3u) == 0u;
-                for (uint32_t g = tid; 4u * g < TS; g += nthr) {
-                    uint32_t v = S0 + 4u * g, w4 = 0;
+                auto one_dword = [&](uint32_t v) {                                 // image dword at tile offset v - S0 (a multiple of 4)
+                    const uint32_t dst = stage + (v - S0);
+                    uint32_t w4 = 0;
                     bool done = false;
                     if (rows4 && v + 4u <= a.n_sym) {
                         const uint32_t chunk = fdiv(v, a.div_A), base = chunk * a.il_A, rem = v - base, take = min(a.il_A, a.n_sym - base);
@@ -836,7 +837,35 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
                             w4 |= lds_u8(a.sym_off + (u - u_lo)) << (8u * q);
                         }
                     }
-                    *T3_LDS_WPTR(uint32_t, stage + 4u * g) = w4;
+                    *T3_LDS_WPTR(uint32_t, dst) = w4;
+                };
+                if (rows4 && (a.il_w & 15u) == 0u && ((a.il_A & 15u) == 0u || a.il_A >= a.n_sym)) {
+                    // rows are multiples of 16 symbols: one lane = one 16-byte granule of the stream (aligned in stream coordinates, so it
+                    // lies inside one row): one row computation per 16 symbols; the tile's ragged ends go dword by dword
+                    const uint32_t g0 = S0 & ~15u;
+                    for (uint32_t q = tid; g0 + 16u * q < S0 + TS; q += nthr) {
+                        const uint32_t v = g0 + 16u * q;
+                        if (v >= S0 && v + 16u <= S0 + TS && v + 16u <= a.n_sym) {
+                            const uint32_t chunk = fdiv(v, a.div_A), base = chunk * a.il_A, rem = v - base, take = min(a.il_A, a.n_sym - base);
+                            const uint32_t r = fdiv(rem, a.div_w), rw = r * a.il_w, c = rem - rw, rowlen = min(a.il_w, take - rw);
+                            if (!(r & 1u) || rowlen == a.il_w) {
+                                const uint32_t src = (r & 1u) ? base + rw + (a.il_w - 16u - c) : v;
+                                const u32x4 x = *T3_LDS_PTR(u32x4, a.sym_off + (src - u_lo));           // 16-byte aligned: rows start at multiples of 16 from u_lo
+                                const uint32_t dst = stage + (v - S0);                                  // only 4-byte aligned (tile edges are multiples of 4)
+                                if (r & 1u) {
+                                    *T3_LDS_WPTR(u32x2a4, dst) = u32x2a4{__builtin_bswap32(x.w), __builtin_bswap32(x.z)};
+                                    *T3_LDS_WPTR(u32x2a4, dst + 8u) = u32x2a4{__builtin_bswap32(x.y), __builtin_bswap32(x.x)};
+                                } else {
+                                    *T3_LDS_WPTR(u32x2a4, dst) = u32x2a4{x.x, x.y};
+                                    *T3_LDS_WPTR(u32x2a4, dst + 8u) = u32x2a4{x.z, x.w};
+                                }
+                                continue;
+                            }
+                        }
+                        for (uint32_t d = 0; d < 4u; ++d) { const uint32_t vd = v + 4u * d; if (vd >= S0 && vd < S0 + TS) one_dword(vd); }
+                    }
+                } else {
+                    for (uint32_t g = tid; 4u * g < TS; g += nthr) one_dword(S0 + 4u * g);
                 }
                 barrier_lds();
                 symb = stage;
