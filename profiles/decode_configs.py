@@ -12,7 +12,7 @@ W, H = 7680, 4320; NPX = W * H
 px = ol.oracle().lcg_pixels(NPX, 12345)
 d_px = torch.from_numpy(px.view(np.uint8)).cuda()
 s = torch.cuda.current_stream().cuda_stream
-def run(name, cfg, errors=False):
+def run(name, cfg, errors=False, words=False):
     n_raw = NPX // 2
     n_enc = t3.encoded_words(n_raw, cfg)
     coded = torch.zeros(n_enc * 9 + 64, dtype=torch.uint8, device="cuda")
@@ -22,16 +22,21 @@ def run(name, cfg, errors=False):
         t3.inject_errors_dev(coded.data_ptr(), L.header_syms, L.body_syms // 26, 4242, (26 - max(L.band_k)) // 2, s)
     out = torch.zeros(NPX * 6 + 64, dtype=torch.uint8, device="cuda")
     seen = t3.default_cfg(); seen.mode = cfg.mode
-    f = lambda: t3.decode_profile_dev(coded.data_ptr(), n_enc, seen, out.data_ptr(), NPX, True, s)
+    f = lambda: t3.decode_profile_dev(coded.data_ptr(), n_enc, seen, out.data_ptr(), NPX if not words else n_raw, not words, s)
     for _ in range(2): f()
     torch.cuda.synchronize()
-    ok = bool(torch.equal(out[:NPX * 6], d_px[:NPX * 6]))
+    if words:
+        raw = torch.zeros(n_raw * 9 + 64, dtype=torch.uint8, device="cuda")
+        t3.pack_pixels_dev(d_px.data_ptr(), NPX, raw.data_ptr(), s); torch.cuda.synchronize()
+        ok = bool(torch.equal(out[:n_raw * 9], raw[:n_raw * 9]))
+    else:
+        ok = bool(torch.equal(out[:NPX * 6], d_px[:NPX * 6]))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5): f()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
-    return {"config": name, "ms": round(ms, 4), "pixels_exact": ok, "GBps": round((6 * NPX + 9 * n_enc) / ms / 1e6, 1)}
+    return {"config": name, "ms": round(ms, 4), "pixels_exact": ok, "GBps": round(((9 * n_raw if words else 6 * NPX) + 9 * n_enc) / ms / 1e6, 1)}
 P = t3.ProfileID; F = t3.MODE_FIXED
 res = []
 res.append(run("C2 FIXED RS(26,20) 1-D (fused decoder), clean stream", t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=F)))
@@ -41,4 +46,6 @@ res.append(run("C3 FIXED 2-D 64x64 + luma UEP (two-kernel decoder), clean", t3.m
 res.append(run("C2 FIXED + beacon every 64 words (strip pass + fused decoder), clean", t3.make_cfg(profile=P.P3_RS26_20, uep=2, beacon=(64, 4, 1), mode=F)))
 res.append(run("C2 FIXED RS(26,20) 1-D (fused decoder), 0..3 errors per block", t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=F), errors=True))
 res.append(run("C3 FIXED 2-D 64x64 + luma UEP (two-kernel decoder), 0..2 errors per block", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F), errors=True))
+res.append(run("C2 FIXED RS(26,20) 1-D (fused decoder) to raw words, clean stream", t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=F), words=True))
+res.append(run("C3 FIXED 2-D 64x64 + luma UEP (two-kernel decoder) to raw words, clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F), words=True))
 print(json.dumps(res, indent=1))

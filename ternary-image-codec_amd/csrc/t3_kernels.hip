@@ -778,13 +778,18 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     // result back at once (s_waitcnt vmcnt(0): the atomic's round trip plus the acknowledgement of the wave's stores of the
     // previous tile).  On thread 0 that stall sat in front of phase 1's conversion, on the critical path of every tile; the
     // last wave has no conversion work (pixels), and is taken off prefetch duty so that the wait does not cover a DMA either.
-    const bool drawer = dyn && tid == (nwv - 1u) * 64u;
     const bool excl = dyn && w0 + 1u < nwv;                                    // the drawing wave issues no prefetch
     const uint32_t n_pf = nwv - w0 - (excl ? 1u : 0u);
-    uint32_t pend = 0;                                                         // drawer: ticket of the tile two after the current one
-    if (drawer) pend = atomicAdd(ctr, 1u);
-    uint32_t par = 0;
-    for (uint32_t tile = blockIdx.x, nxt = dyn ? cls + NC * (wgc + blockIdx.x / NC) : blockIdx.x + gridDim.x, nn = 0; tile < a.n_tiles; tile = nxt, nxt = nn, par ^= 1u) {
+    // The roles rotate from tile to tile: a "virtual" wave index vw = wave - rot (mod nwv) decides who converts (vw < w0),
+    // who prefetches and who draws (vw = nwv - 1), and rot advances by w0 per tile.  Waves sit on SIMD (wave mod 4) for the
+    // whole kernel; with fixed roles the conversion -- more than half of the kernel's VALU work -- always ran on the same
+    // three SIMDs of a CU and those bounded the tile rate.  The pending ticket travels through LDS (slot 332).
+    if (dyn && tid == (nwv - 1u) * 64u) *(uint32_t*)(lds + 332) = atomicAdd(ctr, 1u);     // ticket of the tile two after the first one
+    uint32_t par = 0, rot = 0;
+    for (uint32_t tile = blockIdx.x, nxt = dyn ? cls + NC * (wgc + blockIdx.x / NC) : blockIdx.x + gridDim.x, nn = 0; tile < a.n_tiles;
+         tile = nxt, nxt = nn, par ^= 1u, rot = (rot + w0 >= nwv ? rot + w0 - nwv : rot + w0)) {
+        const uint32_t vw = fast ? (wave >= rot ? wave - rot : wave + nwv - rot) : wave;
+        const bool drawer = dyn && lane == 0u && vw == nwv - 1u;
         const uint32_t S0 = tile * TS;
         const uint32_t stage = a.stage_off + (fast ? par * a.stage_stride : 0u);
         uint32_t symb = a.sym_off;                                            // where phase 2 finds the tile's symbols
@@ -795,17 +800,17 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             uint32_t ticket = 0;
             if (drawer) ticket = atomicAdd(ctr, 1u);                          // drawn three tiles ahead
 #ifndef T3_ABL_NO_PREFETCH
-            if (nxt < a.n_tiles && wave >= w0 && wave - w0 < n_pf)
-                stage_input<FE>(a, a.stage_off + (par ^ 1u) * a.stage_stride, first_group(need_lo(nxt * TS)), (need_hi(nxt * TS) + GS - 1u) / GS, lane, wave - w0, n_pf);
+            if (nxt < a.n_tiles && vw >= w0 && vw - w0 < n_pf)
+                stage_input<FE>(a, a.stage_off + (par ^ 1u) * a.stage_stride, first_group(need_lo(nxt * TS)), (need_hi(nxt * TS) + GS - 1u) / GS, lane, vw - w0, n_pf);
 #endif
             T3_STAMP(4);
 #ifndef T3_ABL_NO_P1
             const uint32_t u_lo = need_lo(S0), u_hi = need_hi(S0);
-            if constexpr (FE == FE_PIXELS) convert_pixels_packed<(1 << SH)>(a, stage, ((uint64_t)first_group(u_lo) * kGroupBytes) & ~15ull, u_lo, u_hi, lane, wave, nwv);
-            else convert_groups<FE, false, SH>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, tid, nthr);
+            if constexpr (FE == FE_PIXELS) convert_pixels_packed<(1 << SH)>(a, stage, ((uint64_t)first_group(u_lo) * kGroupBytes) & ~15ull, u_lo, u_hi, lane, vw, nwv);
+            else convert_groups<FE, false, SH>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, vw * 64u + lane, nthr);
 #endif
             T3_STAMP(5);                                                      // (diagnostic) this wave's conversion
-            if (drawer) { *(uint32_t*)(lds + 328) = cls + NC * (2u * wgc + pend); pend = ticket; }
+            if (drawer) { *(uint32_t*)(lds + 328) = cls + NC * (2u * wgc + *(const uint32_t*)(lds + 332)); *(uint32_t*)(lds + 332) = ticket; }
             barrier_lds();                                                    // symbols complete
             T3_STAMP(1);
             nn = dyn ? __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + 328)) : nxt + gridDim.x;   // the tile after the next one
@@ -943,8 +948,8 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 #endif
         T3_STAMP(2);
     }
-    if (drawer) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this workgroup's last ticket draw has completed
+    if (dyn && tid == (nwv - 1u) * 64u) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (every draw was read back by its wave right away)
         if (atomicAdd(a.tile_ctr + 64u * NC, 1u) == gridDim.x - 1u) {          // ... and so has everyone else's: re-arm for the next launch
             for (uint32_t c = 0; c <= NC; ++c) __hip_atomic_store(a.tile_ctr + 64u * c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
