@@ -69,8 +69,10 @@ def cpu_baseline(orc, ol, px, budget_s=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: the card needs about a hundred steps (40 ms of continuous work) to settle at its sustained clock; with 20 steps
+    # after 3 of warm-up every kernel measured 10-15 % slower (profiles/r01/notes.md).  300 steps are 0.1 s of GPU time.
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--encode-only", action="store_true", help="profiling aid: skip decode + index in the loop")
     ap.add_argument("--serial", action="store_true", help="index record on the main stream instead of overlapping it with the decode")

@@ -11,10 +11,10 @@ cd "$(dirname "$0")/.."; export TMPDIR=/tmp
 tag=${1:-x}
 timeout -k 10 600 python3 -m pytest tests -m gpu -q > gpurun_out/${tag}_pytest.log 2>&1; tail -2 gpurun_out/${tag}_pytest.log
 python3 bench.py 2> gpurun_out/${tag}_bench.err | tail -1 > gpurun_out/${tag}_bench.json; cut -c1-400 gpurun_out/${tag}_bench.json
-rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_kt -o kt --output-format csv -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/${tag}_kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_kt -o kt --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/${tag}_kt.log 2>&1
 cp gpurun_out/${tag}_kt/kt_kernel_stats.csv gpurun_out/${tag}_kernel_stats.csv 2>/dev/null; head -7 gpurun_out/${tag}_kernel_stats.csv | cut -c1-160
 # the same with the index record on the main stream: every kernel runs alone (its stand-alone duration)
-rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_kts -o kt --output-format csv -- python3 bench.py --serial --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/${tag}_kts.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_kts -o kt --output-format csv -- python3 bench.py --serial --no-cpu-baseline > gpurun_out/${tag}_kts.log 2>&1
 cp gpurun_out/${tag}_kts/kt_kernel_stats.csv gpurun_out/${tag}_kernel_stats_serial.csv 2>/dev/null; head -6 gpurun_out/${tag}_kernel_stats_serial.csv | cut -c1-160
 bash profiles/pmc_encode.sh ${tag} > gpurun_out/${tag}_pmc.txt 2>&1
 bash profiles/pmc_decode.sh ${tag} > gpurun_out/${tag}_pmcd.txt 2>&1      # SQ counters of the decoder / CRC kernels -> gpurun_out/pmcd_${tag}_summary.json
