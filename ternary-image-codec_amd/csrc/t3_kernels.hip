@@ -407,16 +407,17 @@ __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t symb,
         // Lane (n, h) holds bytes [8s + 4h, +4) of block n.  Two half-wave exchanges give the lower lane bytes 0..15 and the
         // upper lane bytes 10..25 of the block: ONE 16-byte store per lane covers the 26 bytes (bytes 10..15 are written by
         // both, with the same values), instead of three scattered dwords and a short -- an eighth of the cache-line requests.
-        const auto sw = __builtin_amdgcn_permlane32_swap(W0, W2, false, false);   // upper half of W0 (bytes 4..7) <-> lower half of W2 (bytes 16..19)
-        const uint32_t Xa = sw[0], Xb = sw[1];                                    // h=0: Xa = bytes 0..3, Xb = 4..7;   h=1: Xa = 16..19, Xb = 20..23
-        const auto sw1 = __builtin_amdgcn_permlane32_swap(s.W[1], s.W[1], false, false);
-        const uint32_t oW1 = h ? sw1[0] : sw1[1];                                  // the partner's W[1]: h=0 gets bytes 12..15, h=1 bytes 8..11
-        const uint32_t S0 = h ? s.W[1] : Xa, S1 = h ? Xa : Xb, S2 = h ? Xb : s.W[1];   // h=0: 0..3, 4..7, 8..11;  h=1: 12..15, 16..19, 20..23
+        // v_permlane32_swap(a, b): a's upper half-wave <-> b's lower half-wave.  swap(W0, W1) and swap(W1, W2) leave in every lane the
+        // four dwords of its 16-byte run in order -- h=0: bytes 0..3, 4..7, 8..11, 12..15; h=1: 8..11, 12..15, 16..19, 20..23 --
+        // and one v_perm per dword with a per-lane selector takes them as they are (h=0) or shifted by two bytes (h=1: bytes 10..25).
+        const auto q01 = __builtin_amdgcn_permlane32_swap(W0, s.W[1], false, false);
+        const auto q23 = __builtin_amdgcn_permlane32_swap(s.W[1], W2, false, false);
+        const uint32_t selE = h ? 0x05040302u : 0x03020100u;                      // v_perm(S0, S1): 0..3 = bytes of S1, 4..7 = bytes of S0
         U128a2 E;
-        E.v[0] = h ? __builtin_amdgcn_alignbit(S0, oW1, 16) : S0;                  // h=1: bytes 10..13
-        E.v[1] = h ? __builtin_amdgcn_alignbit(S1, S0, 16) : S1;
-        E.v[2] = h ? __builtin_amdgcn_alignbit(S2, S1, 16) : S2;
-        E.v[3] = h ? __builtin_amdgcn_alignbit(tail, S2, 16) : oW1;                // h=1: bytes 22..25
+        E.v[0] = __builtin_amdgcn_perm(q01[1], q01[0], selE);
+        E.v[1] = __builtin_amdgcn_perm(q23[0], q01[1], selE);
+        E.v[2] = __builtin_amdgcn_perm(q23[1], q23[0], selE);
+        E.v[3] = __builtin_amdgcn_perm(tail, q23[1], selE);                        // h=1: bytes 22..25
 #ifdef T3_ABL_NO_STORE
         if (s.valid && a.n_tiles == 0xFFFFFFFFu)
 #else
@@ -615,15 +616,16 @@ __device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, uint32_t
 #pragma unroll
         for (uint32_t pair = 0; pair < 2; ++pair) {                               // pair 0 = triples (0, 2), pair 1 = triples (1, 3)
             u16x2 h[9], c[9];
-            u16x2 over = {0, 0};
+            u16x2 mxY = {0, 0}, mxC = {0, 0};                                    // range check on the maxima: one comparison per kind instead of one per component
 #pragma unroll
             for (uint32_t i = 0; i < 9; ++i) {
                 const uint32_t u = 9u * pair + i;                                 // 16-bit index of the low-half component; the high half sits 18 further
                 const uint32_t w = __builtin_amdgcn_perm(D[9u + u / 2u], D[u / 2u], (u & 1u) ? 0x07060302u : 0x05040100u);
                 h[i] = __builtin_bit_cast(u16x2, w);
                 c[i] = (i % 3 == 0) ? h[i] : h[i] + (uint16_t)40;
-                over |= __builtin_elementwise_sub_sat(c[i], (u16x2)((uint16_t)((i % 3 == 0) ? 242 : 80)));
+                if (i % 3 == 0) mxY = __builtin_elementwise_max(mxY, c[i]); else mxC = __builtin_elementwise_max(mxC, c[i]);
             }
+            const u16x2 over = __builtin_elementwise_sub_sat(mxY, (u16x2)((uint16_t)242)) | __builtin_elementwise_sub_sat(mxC, (u16x2)((uint16_t)80));
             if (__builtin_amdgcn_ballot_w64(live && (pk_bits(over) & (pair ? liveB : liveA)) != 0u) != 0) {   // out-of-range quantised values: exact general reduction
 #pragma unroll
                 for (uint32_t i = 0; i < 9; ++i) {
