@@ -4,7 +4,7 @@ import torch, json
 n = 198_000_000
 src = torch.empty(n, dtype=torch.uint8, device="cuda").random_(0, 255)
 dst = torch.empty_like(src)
-for _ in range(5): dst.copy_(src)
+for _ in range(600): dst.copy_(src)          # ~45 ms: the card settles at its sustained clock (profiles/r01/notes.md)
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
 ev[0].record()
