@@ -73,6 +73,7 @@ def main():
     # after 3 of warm-up every kernel measured 10-15 % slower (profiles/r01/notes.md).  300 steps are 0.1 s of GPU time.
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--settle-ms", type=float, default=80.0, help="untimed clock-settling work before the warm-up steps (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--encode-only", action="store_true", help="profiling aid: skip decode + index in the loop")
     ap.add_argument("--serial", action="store_true", help="index record on the main stream instead of overlapping it with the decode")
@@ -159,6 +160,15 @@ def main():
         if s2 is None:
             t3.frame_record_dev(*rec_args, stream)
 
+    # clock settling, untimed and in addition to the W warm-up steps: the card needs tens of milliseconds of continuous work to
+    # reach its sustained clock (profiles/r01/notes.md); without it a short run (small K and W) measures the ramp, 10-15 % slow
+    settle_steps = 0
+    if args.settle_ms > 0:
+        t_s = time.perf_counter()
+        while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
+            for _ in range(8):
+                step(settle_steps % max(args.steps, 1)); settle_steps += 1
+            torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -217,7 +227,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "one 7680x4320 frame per rank per step (BASELINE configs[1]): fused encode COMPAT P3 RS(26,20) 1-D, then FIXED-mode decode of the same frame with 0..3 injected symbol errors per block (" + ("synchronous entry, header parsed on the host per frame" if args.sync_decode else "streaming entry: configuration from the stream's first frame, header symbols checked on the device") + "), then index record" + (" [encode only]" if args.encode_only else ""),
-                   "frame_px": NPX, "coded_words": n_enc, "sharding": "frames per rank, no data-path collective; one all-gather of index records per batch"},
+                   "frame_px": NPX, "coded_words": n_enc, "settle_ms": args.settle_ms, "settle_steps": settle_steps, "sharding": "frames per rank, no data-path collective; one all-gather of index records per batch"},
         "encode_ms": round(enc_avg, 4), "decode_ms": round(dec_avg, 4),
         "encode_mpix_s": round(NPX / enc_avg / 1e3, 1), "decode_mpix_s": round(NPX / dec_avg / 1e3, 1),
         "roofline": {"kernel": "encode_kernel_k<FE_PIXELS, 1-D, r=6>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
