@@ -59,9 +59,15 @@ __global__ __launch_bounds__(256) void quant_to_rgb_kernel(const uint16_t* __res
     const uint64_t p0 = 4 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
     if (p0 >= n_px) return;
     uint8_t o[12];
+    uint16_t in[12];
+    if (p0 + 4 <= n_px && ((uintptr_t)px & 7u) == 0) {                       // three aligned 8-byte loads
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const uint2 v = *(const uint2*)(px + 3 * p0 + 4 * k); in[4 * k] = (uint16_t)v.x; in[4 * k + 1] = (uint16_t)(v.x >> 16); in[4 * k + 2] = (uint16_t)v.y; in[4 * k + 3] = (uint16_t)(v.y >> 16); }
+    } else for (uint32_t i = 0; i < 12; ++i) in[i] = 3 * p0 + i < 3 * n_px ? px[3 * p0 + i] : (uint16_t)0;
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (p0 + q >= n_px) { o[3 * q] = o[3 * q + 1] = o[3 * q + 2] = 0; continue; }
-        const uint32_t Yq = px[3 * (p0 + q)]; const int Cbq = (int16_t)px[3 * (p0 + q) + 1], Crq = (int16_t)px[3 * (p0 + q) + 2];
+        const uint32_t Yq = in[3 * q]; const int Cbq = (int16_t)in[3 * q + 1], Crq = (int16_t)in[3 * q + 2];
         // dequantize_ycbcr :79-84 (tables cover the in-range values; beyond them the clamps decide)
         const int Y = Yq >= 242u ? 255 : T.yd[Yq];
         const int Cb = Cbq <= -40 ? 0 : (Cbq >= 40 ? 255 : T.cd[Cbq + 40]), Cr = Crq <= -40 ? 0 : (Crq >= 40 ? 255 : T.cd[Crq + 40]);
