@@ -333,7 +333,7 @@ int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, vo
     if (L.out_words && !d_out) return T3_E_ARG;
     if (cfg->profile == T3_RAW_MODE) {                                   // OLD:1046-1050: out = in
         if (fe == FE_WORDS) { if (n_raw) HIPCHK(hipMemcpyAsync(d_out, d_in, n_raw * 9, hipMemcpyDeviceToDevice, s)); }
-        else if (n_raw) { hipLaunchKernelGGL(pack_pixels_kernel, dim3((unsigned)((n_raw + 255) / 256)), dim3(256), 0, s, (const uint16_t*)d_in, n_units, (uint8_t*)d_out, n_raw); HIPCHK(hipGetLastError()); }
+        else if (n_raw) { hipLaunchKernelGGL(pack_pixels_kernel, dim3((unsigned)(((n_raw + 3) / 4 + 255) / 256)), dim3(256), 0, s, (const uint16_t*)d_in, n_units, (uint8_t*)d_out, n_raw); HIPCHK(hipGetLastError()); }
         return T3_OK;
     }
     std::lock_guard<std::mutex> lk(g.mu);
@@ -490,14 +490,14 @@ int t3hip_pack_pixels_dev(const void* d_px, uint64_t n_px, void* d_words, void* 
     if (!g.ready) return T3_E_NODEVICE;
     const uint64_t nw = (n_px + 1) / 2; if (!nw) return T3_OK;
     if (!d_px || !d_words) return T3_E_ARG;
-    hipLaunchKernelGGL(pack_pixels_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)d_px, n_px, (uint8_t*)d_words, nw);
+    hipLaunchKernelGGL(pack_pixels_kernel, dim3((unsigned)(((nw + 3) / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)d_px, n_px, (uint8_t*)d_words, nw);
     HIPCHK(hipGetLastError()); return T3_OK;
 }
 int t3hip_unpack_words_dev(const void* d_words, uint64_t n_words, void* d_px, void* stream) {
     if (!g.ready) return T3_E_NODEVICE;
     if (!n_words) return T3_OK;
     if (!d_px || !d_words) return T3_E_ARG;
-    hipLaunchKernelGGL(unpack_words_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_words, n_words, (uint16_t*)d_px);
+    hipLaunchKernelGGL(unpack_words_kernel, dim3((unsigned)(((n_words + 3) / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_words, n_words, (uint16_t*)d_px);
     HIPCHK(hipGetLastError()); return T3_OK;
 }
 int t3hip_encode_profile_dev(const void* d_raw, uint64_t n_raw, const t3_cfg* cfg, void* d_out, uint64_t cap, uint64_t* n_out, void* stream) {

@@ -94,27 +94,52 @@ __device__ __forceinline__ void px2_to_word(const uint32_t* c /*6 reduced comps*
     s[8] = div9(R1);
 }
 
-__global__ __launch_bounds__(256) void pack_pixels_kernel(const uint16_t* __restrict__ px, uint64_t n_px, uint8_t* __restrict__ words, uint64_t n_words) {
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words) return;
+// One lane = four words: 48 bytes of pixels in (three 16-byte loads), 36 bytes out (nine dwords); the frame's last lanes and
+// unaligned buffers go element by element.
+__device__ __forceinline__ void pack_one(const uint16_t* h /*6 components; nullptr-free*/, uint32_t n_valid_px, uint32_t* s) {
     uint32_t c[6];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const uint64_t p = 2 * w + i;
-        if (p < n_px) { c[3 * i] = red_y(px[3 * p]); c[3 * i + 1] = red_c(px[3 * p + 1]); c[3 * i + 2] = red_c(px[3 * p + 2]); }
+        if ((uint32_t)i < n_valid_px) { c[3 * i] = red_y(h[3 * i]); c[3 * i + 1] = red_c(h[3 * i + 1]); c[3 * i + 2] = red_c(h[3 * i + 2]); }
         else { c[3 * i] = 0; c[3 * i + 1] = 40; c[3 * i + 2] = 40; }     // PixelYCbCrQuant{} pad (OLD:730)
     }
-    uint32_t s[9]; px2_to_word(c, s);
+    px2_to_word(c, s);
+}
+__global__ __launch_bounds__(256) void pack_pixels_kernel(const uint16_t* __restrict__ px, uint64_t n_px, uint8_t* __restrict__ words, uint64_t n_words) {
+    const uint64_t w0 = 4 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    if (w0 >= n_words) return;
+    if (2 * w0 + 8 <= n_px && w0 + 4 <= n_words && (((uintptr_t)px | (uintptr_t)words) & 15u) == 0) {
+        uint32_t in[12];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) words[9 * w + i] = (uint8_t)s[i];
+        for (int k = 0; k < 3; ++k) { const uint4 v = *(const uint4*)(px + 6 * w0 + 8 * k); in[4 * k] = v.x; in[4 * k + 1] = v.y; in[4 * k + 2] = v.z; in[4 * k + 3] = v.w; }
+        uint32_t o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            uint16_t h[6];
+#pragma unroll
+            for (uint32_t i = 0; i < 6; ++i) { const uint32_t e = 6u * q + i; h[i] = (uint16_t)(in[e >> 1] >> (16u * (e & 1u))); }
+            uint32_t sy[9]; pack_one(h, 2, sy);
+#pragma unroll
+            for (uint32_t i = 0; i < 9; ++i) { const uint32_t b = 9u * q + i; o[b >> 2] |= (sy[i] & 0xFFu) << (8u * (b & 3u)); }
+        }
+        uint32_t* d = (uint32_t*)(words + 9 * w0);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) d[k] = o[k];
+        return;
+    }
+    for (uint64_t w = w0; w < min(w0 + 4, n_words); ++w) {
+        uint16_t h[6] = {0, 0, 0, 0, 0, 0};
+        const uint32_t nv = (uint32_t)min((uint64_t)2, n_px > 2 * w ? n_px - 2 * w : 0ull);
+        for (uint32_t i = 0; i < 3u * nv; ++i) h[i] = px[6 * w + i];
+        uint32_t sy[9]; pack_one(h, nv, sy);
+        for (int i = 0; i < 9; ++i) words[9 * w + i] = (uint8_t)sy[i];
+    }
 }
 
-__global__ __launch_bounds__(256) void unpack_words_kernel(const uint8_t* __restrict__ words, uint64_t n_words, uint16_t* __restrict__ px) {
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words) return;
+__device__ __forceinline__ void unpack_one(const uint32_t* craw, uint16_t* o) {
     uint32_t c[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) c[i] = mod27(words[9 * w + i]);           // unpack3 reduces each digit (OLD:28-31)
+    for (int i = 0; i < 9; ++i) c[i] = mod27(craw[i]);                     // unpack3 reduces each digit (OLD:28-31)
     // inverse of px2_to_word; trit 26 (= c[8]/9) is ignored (OLD:716-721)
     const uint32_t Y0 = c[0] + 27u * mod9(c[1]);
     const uint32_t B0 = div9(c[1]) + 3u * c[2];
@@ -122,9 +147,39 @@ __global__ __launch_bounds__(256) void unpack_words_kernel(const uint8_t* __rest
     const uint32_t Y1 = div3(c[4]) + 9u * c[5];
     const uint32_t B1 = c[6] + 27u * mod3(c[7]);
     const uint32_t R1 = div3(c[7]) + 9u * mod9(c[8]);
-    uint16_t* o = px + 6 * w;
     o[0] = (uint16_t)Y0; o[1] = (uint16_t)(int16_t)((int)B0 - 40); o[2] = (uint16_t)(int16_t)((int)R0 - 40);
     o[3] = (uint16_t)Y1; o[4] = (uint16_t)(int16_t)((int)B1 - 40); o[5] = (uint16_t)(int16_t)((int)R1 - 40);
+}
+// One lane = four words: nine dwords in, three 16-byte stores of pixels out.
+__global__ __launch_bounds__(256) void unpack_words_kernel(const uint8_t* __restrict__ words, uint64_t n_words, uint16_t* __restrict__ px) {
+    const uint64_t w0 = 4 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    if (w0 >= n_words) return;
+    if (w0 + 4 <= n_words && (((uintptr_t)px | (uintptr_t)words) & 15u) == 0) {
+        uint32_t in[9];
+        const uint32_t* sdw = (const uint32_t*)(words + 9 * w0);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) in[k] = sdw[k];
+        uint32_t o[12];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            uint32_t c[9];
+#pragma unroll
+            for (uint32_t i = 0; i < 9; ++i) { const uint32_t b = 9u * q + i; c[i] = (in[b >> 2] >> (8u * (b & 3u))) & 0xFFu; }
+            uint16_t h[6]; unpack_one(c, h);
+#pragma unroll
+            for (uint32_t i = 0; i < 3; ++i) o[3u * q + i] = (uint32_t)h[2 * i] | (uint32_t)h[2 * i + 1] << 16;
+        }
+        uint4* d = (uint4*)(px + 6 * w0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+        return;
+    }
+    for (uint64_t w = w0; w < min(w0 + 4, n_words); ++w) {
+        uint32_t c[9];
+        for (int i = 0; i < 9; ++i) c[i] = words[9 * w + i];
+        uint16_t h[6]; unpack_one(c, h);
+        for (int i = 0; i < 6; ++i) px[6 * w + i] = h[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -346,6 +346,30 @@ def test_subword_dev_entry_points_full_frame(t3, orc, gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("off", [2, 6, 8])
+def test_pack_unpack_dev_unaligned(t3, orc, gpu, off):
+    """K1 / K5 through the device entry points on buffers that are not 16-byte aligned, odd pixel counts included."""
+    import torch
+    rng = np.random.default_rng(40 + off)
+    s = torch.cuda.current_stream().cuda_stream
+    for n in (1, 5, 8, 1001, 40_003):
+        px = rand_pixels(rng, n, in_range=(n != 1001))
+        nw = (n + 1) // 2
+        want = np.asarray(orc.pack_pixels(px)).reshape(-1)
+        d_px = torch.zeros(6 * n + 64, dtype=torch.uint8, device="cuda"); d_px[off: off + 6 * n] = torch.from_numpy(px.view(np.uint8).reshape(-1)).cuda()
+        d_w = torch.zeros(9 * nw + 64, dtype=torch.uint8, device="cuda")
+        t3.pack_pixels_dev(d_px.data_ptr() + off, n, d_w.data_ptr() + off - 1, s)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_w[off - 1: off - 1 + 9 * nw].cpu().numpy(), want), (n, off)
+        assert int(d_w[off - 1 + 9 * nw:].max()) == 0 and (off == 1 or int(d_w[: off - 1].max()) == 0)
+        d_b = torch.zeros(12 * nw + 64, dtype=torch.uint8, device="cuda")
+        t3.unpack_words_dev(d_w.data_ptr() + off - 1, nw, d_b.data_ptr() + off, s)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_b[off: off + 12 * nw].cpu().numpy(), np.asarray(orc.unpack_words(orc.pack_pixels(px))).view(np.uint8).reshape(-1)), (n, off)
+        assert int(d_b[off + 12 * nw:].max()) == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("off", [1, 2, 6])
 def test_subword_dev_entry_points_unaligned(t3, orc, gpu, off):
     """Device buffers that are not 16-byte aligned take the byte-wise load/store branches of the staged kernels."""
