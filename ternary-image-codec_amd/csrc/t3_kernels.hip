@@ -840,8 +840,9 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     // The roles rotate from tile to tile: a "virtual" wave index vw = wave - rot (mod nwv) decides who converts (vw < w0),
     // who prefetches and who draws (vw = nwv - 1), and rot advances by w0 per tile.  Waves sit on SIMD (wave mod 4) for the
     // whole kernel; with fixed roles the conversion -- more than half of the kernel's VALU work -- always ran on the same
-    // three SIMDs of a CU and those bounded the tile rate.  The pending ticket travels through LDS (slot 332).
-    if (dyn && tid == (nwv - 1u) * 64u) *(uint32_t*)(lds + 332) = atomicAdd(ctr, 1u);     // ticket of the tile two after the first one
+    // three SIMDs of a CU and those bounded the tile rate.  A ticket is drawn at the top of a tile and names the tile two after
+    // it (its input is requested at the top of the next tile): the drawing wave reads the atomic back at once anyway, so
+    // holding the ticket for one more tile only made the workgroups commit a tile earlier than needed (longer tail).
     uint32_t par = 0, rot = 0;
     for (uint32_t tile = blockIdx.x, nxt = dyn ? cls + NC * (wgc + blockIdx.x / NC) : blockIdx.x + gridDim.x, nn = 0; tile < a.n_tiles;
          tile = nxt, nxt = nn, par ^= 1u, rot = (rot + w0 >= nwv ? rot + w0 - nwv : rot + w0)) {
@@ -854,8 +855,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
         if (fast) {
             barrier_input(younger);                                           // this tile's input has landed, everyone left phase 2
             T3_STAMP(0);
-            uint32_t ticket = 0;
-            if (drawer) ticket = atomicAdd(ctr, 1u);                          // drawn three tiles ahead
+            if (drawer) *(uint32_t*)(lds + 328) = cls + NC * (2u * wgc + atomicAdd(ctr, 1u));   // the tile after the next one (read after the barrier below)
 #ifndef T3_ABL_NO_PREFETCH
             if (nxt < a.n_tiles && vw >= w0 && vw - w0 < n_pf)
                 stage_input<FE>(a, a.stage_off + (par ^ 1u) * a.stage_stride, first_group(need_lo(nxt * TS)), (need_hi(nxt * TS) + GS - 1u) / GS, lane, vw - w0, n_pf);
@@ -867,7 +867,6 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             else convert_groups<FE, false, SH>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, vw * 64u + lane, nthr);
 #endif
             T3_STAMP(5);                                                      // (diagnostic) this wave's conversion
-            if (drawer) { *(uint32_t*)(lds + 328) = cls + NC * (2u * wgc + *(const uint32_t*)(lds + 332)); *(uint32_t*)(lds + 332) = ticket; }
             barrier_lds();                                                    // symbols complete
             T3_STAMP(1);
             nn = dyn ? __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + 328)) : nxt + gridDim.x;   // the tile after the next one
