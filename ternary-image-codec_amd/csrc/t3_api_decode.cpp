@@ -355,8 +355,7 @@ int t3hip_decode_frame_async(const void* d_in, uint64_t n_in, const t3_cfg* cfg,
         }
         d_exp = it->second;
     }
-    HIPCHK(hipMemsetAsync(d_verdict, 0, 8, s));
-    hipLaunchKernelGGL(hdr_compare_kernel, dim3(1), dim3(128), 0, s, (const uint8_t*)d_in, d_exp, hs, d_verdict);
+    hipLaunchKernelGGL(hdr_compare_kernel, dim3(1), dim3(128), 0, s, (const uint8_t*)d_in, d_exp, hs, d_verdict);   // also zeroes the block counter
     HIPCHK(hipGetLastError());
     const ScrCycle sc = scrambler_cycle(cfg->seed_a, cfg->seed_b, cfg->seed_s0);
     return decode_body(d_in, n_in, *cfg, n_raw, sc.next, d_out, cap, n_out, to_pixels, d_verdict + 1, s);

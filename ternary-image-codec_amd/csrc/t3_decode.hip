@@ -216,8 +216,10 @@ __global__ __launch_bounds__(256) void crc_chunks_kernel(const CrcArgs a) {
 }
 
 // header symbols of the frame against the ones the previous frame parsed to (speculative decode, t3_api_decode.cpp)
-__global__ void hdr_compare_kernel(const uint8_t* in, const uint8_t* expect, uint32_t n, uint32_t* mismatch) {
-    if (threadIdx.x < n && in[threadIdx.x] != expect[threadIdx.x]) *mismatch = 1u;
+// One workgroup; writes both verdict words: [0] = header differs, [1] = 0 (the body kernels count uncorrectable blocks into it)
+__global__ void hdr_compare_kernel(const uint8_t* in, const uint8_t* expect, uint32_t n, uint32_t* verdict) {
+    const int diff = __syncthreads_or(threadIdx.x < n && in[threadIdx.x] != expect[threadIdx.x]);
+    if (threadIdx.x == 0) { verdict[0] = diff ? 1u : 0u; verdict[1] = 0u; }
 }
 
 __global__ void frame_record_kernel(const CrcArgs a, const uint8_t* words, uint64_t n_words, uint64_t frame_idx, uint32_t profile, uint32_t mode, void* recv) {
