@@ -437,6 +437,8 @@ int t3hip_shutdown(void) {
     for (auto& kv : g.sbuf) if (kv.second.first) (void)hipFree(kv.second.first);
     g.sbuf.clear();
     for (int i = 0; i < 4; ++i) { if (g.buf[i]) (void)hipFree(g.buf[i]); g.buf[i] = nullptr; g.cap[i] = 0; for (int m = 0; m < 2; ++m) { (void)hipFree(g.d_P[i][m]); g.d_P[i][m] = nullptr; } }
+    t3::decode_shutdown();
+    if (g.d_ctr) { (void)hipFree(g.d_ctr); g.d_ctr = nullptr; } g.ctr_slot.clear();
     (void)hipFree(g.d_tab); (void)hipFree(g.d_flag); (void)hipStreamDestroy(g.stream);
     g.ready = false; g.dev = -1;
     return T3_OK;

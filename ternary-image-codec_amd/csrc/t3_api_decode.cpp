@@ -276,6 +276,12 @@ int read_header(const void* d_in, uint64_t n_in, int mode, t3_cfg* seen, uint64_
 }  // namespace
 
 namespace t3 {
+void decode_shutdown() {
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
+    fr(d_zpow); fr(d_crc_acc); fr(d_crc_afrag); fr(d_fxtab); fr(d_fma);
+    for (int i = 0; i < 4; ++i) { fr(d_synd_lut[i]); synd_lut_bytes[i] = 0; fr(d_roots[i]); }
+}
 int decode_init(const RsTables*) {
     // Z[0]: one zero byte through the byte-wise register update; Z[j+1] = Z[j] o Z[j]
     std::vector<uint32_t> z((size_t)kCrcPows * 32);

@@ -103,6 +103,7 @@ struct EmitStArgs {
 struct DebeaconArgs { const uint8_t* framed; uint64_t framed_bytes; uint8_t* body; uint64_t body_syms; uint32_t period, slot; };   // framed_bytes: readable bytes from `framed`
 
 int decode_init(const RsTables* d_tab);
+void decode_shutdown();                       // frees what decode_init and the lazily built decoder tables allocated
 
 #if defined(__HIPCC__)
 __global__ void dec_gather_rs_kernel(const DecArgs a);

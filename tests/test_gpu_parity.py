@@ -553,3 +553,17 @@ def test_rgb_frame_encode_decode(t3, orc, gpu, npx):
     torch.cuda.synchronize()
     assert ver.cpu().numpy().tolist() == [0, 0]
     assert np.array_equal(d_back[: 3 * npx].cpu().numpy(), np.asarray(orc.quant_to_rgb(q)).reshape(-1))
+
+
+@pytest.mark.gpu
+def test_shutdown_and_reinit(t3, orc, gpu):
+    """t3hip_shutdown frees the device tables of both halves of the library; a new t3hip_init rebuilds them."""
+    px = orc.lcg_pixels(5000, 1)
+    cfg, _ = both(gpu, dict(profile=2, uep=2), mode=1)
+    ok, enc = gpu.encode_frame(px, cfg); assert ok
+    crc = t3.crc32(np.arange(300000, dtype=np.uint8))
+    assert t3.lib().t3hip_shutdown() == 0
+    t3.init(0)
+    ok, enc2 = gpu.encode_frame(px, cfg); assert ok and np.array_equal(enc, enc2)
+    ok, back = gpu.decode_frame(enc2, gpu.DecoderContext(mode=1)); assert ok and np.array_equal(back[:5000], px)
+    assert t3.crc32(np.arange(300000, dtype=np.uint8)) == crc
