@@ -66,10 +66,13 @@ def test_bench_two_rank_rehearsal(gpu):
     """bench.py's N>1 control flow (rank-sharded frames, one all-gather of index records, max-over-ranks timing, the index
     assertions) on one card: two ranks on cuda:0, collectives over gloo (T3_BENCH_REHEARSE_ONE_GPU=1).  The driver runs the
     real thing over RCCL on a whole node; this keeps that path from rotting."""
+    import socket
     import sys
+    with socket.socket() as sk:                       # a free rendezvous port
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     env = dict(os.environ, T3_BENCH_REHEARSE_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--settle-ms", "5"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
