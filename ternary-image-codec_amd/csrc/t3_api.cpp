@@ -160,7 +160,10 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     double best_score = -1; uint32_t best_q = 0;
     for (int pass = 0; pass < 2 && !best_q; ++pass) {
         const uint32_t budget = pass == 0 ? 53u * 1024u : 160u * 1024u;     // <= 53 KiB: three workgroups per CU
+        static const uint32_t force_q = getenv("T3HIP_FORCE_Q") ? (uint32_t)atoi(getenv("T3HIP_FORCE_Q")) : 0u;   // measurement knob
         for (uint32_t q = 1; q <= 4096; ++q) {
+            if (force_q && q != force_q && q < force_q) continue;
+            if (force_q && q > force_q) break;
             if (mixed && !grp && (q & 1u)) continue;                     // mixed k, LUT kernel: even multipliers only (measured: odd ones halve its speed)
             const uint64_t Lq = Lk * q; if (9 * Lq > 60000) break;
             uint32_t waves = 0, blocks_total = 0;
