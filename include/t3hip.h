@@ -38,6 +38,7 @@ extern "C" {
 #define T3_E_CAPACITY   -4  /* caller's output buffer is too small                */
 #define T3_E_HEADER     -5  /* header RS / CRC-12 failure  (OLD:920,929-934 -> false) */
 #define T3_E_RS         -6  /* uncorrectable RS block      (OLD:987 -> false)     */
+#define T3_E_COMM       -7  /* RCCL missing or a collective call failed (see t3hip_comm_last_error) */
 
 /* ---- profile ids (OLD:34) -------------------------------------------------- */
 #define T3_P1_RS26_24     0
@@ -217,6 +218,26 @@ int t3hip_crc32_dev(const void* d_data, uint64_t n_bytes, uint32_t* crc_out, voi
 int t3hip_crc32(const void* data, uint64_t n_bytes, uint32_t* crc_out);
 /* Host: sort gathered records by frame_idx and fill byte_offset (T3V index, io_t3p_t3v.cpp:252-289). */
 int t3hip_index_assemble(t3_frame_record* recs, uint64_t n_recs, uint64_t first_payload_offset);
+
+/* ---- multi-GPU exchange step ------------------------------------------------------
+ * Frames shard round-robin over GPUs with no data-path collective; the only exchange is one all-gather of the fixed-size
+ * frame records above, from which every rank assembles the T3V frame index (io_t3p_t3v.cpp:252-289: offset, words per
+ * frame) with t3hip_index_assemble.  The reference has no collective at all; a C++ host does
+ *   rank 0: t3hip_comm_unique_id(id) -> hands the 128 bytes to the other ranks by its own means (file, socket, MPI, ...)
+ *   every rank, after t3hip_init(device): t3hip_comm_create(id, world, rank, &c)         (ncclCommInitRank)
+ *   per batch: t3hip_index_allgather(c, d_local, n_local, d_all, stream)                  (ncclAllGather, asynchronous)
+ * RCCL is bound at run time (dlopen librccl.so.1); without it these return T3_E_COMM. */
+#define T3_COMM_ID_BYTES 128
+typedef struct t3_comm t3_comm;
+int t3hip_comm_unique_id(uint8_t id[T3_COMM_ID_BYTES]);
+int t3hip_comm_create(const uint8_t id[T3_COMM_ID_BYTES], int world, int rank, t3_comm** out);
+int t3hip_comm_destroy(t3_comm* c);
+int t3hip_comm_world(const t3_comm* c);
+int t3hip_comm_rank(const t3_comm* c);
+const char* t3hip_comm_last_error(void);
+/* d_local: n_local records of this rank (device); d_all: world * n_local records (device), rank-major.  Every rank passes the
+ * same n_local (pad with records whose frame_idx == UINT64_MAX). */
+int t3hip_index_allgather(t3_comm* c, const t3_frame_record* d_local, uint64_t n_local, t3_frame_record* d_all, void* stream);
 
 /* ---- subword trit streams and wire packings ------------------------------
  * One byte per trit (0..2) on the trit side.  N = trits kept per word (SubwordMode: 27/24/21/18/15; any 1..27 accepted).

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("T3HIP_LIB", os.path.join(_HERE, "libt3hip.so"))   # T
 
 PIXEL_DT = np.dtype([("Yq", "<u2"), ("Cbq", "<i2"), ("Crq", "<i2")])
 
-OK, E_NODEVICE, E_HIP, E_ARG, E_CAPACITY, E_HEADER, E_RS = 0, -1, -2, -3, -4, -5, -6
+OK, E_NODEVICE, E_HIP, E_ARG, E_CAPACITY, E_HEADER, E_RS, E_COMM = 0, -1, -2, -3, -4, -5, -6, -7
 MODE_COMPAT, MODE_FIXED = 0, 1
 
 
@@ -73,6 +73,8 @@ class T3Error(RuntimeError):
         msg = "%s: %s" % (where, strerror(code))
         if code == E_HIP:
             msg += " [" + last_hip_error() + "]"
+        if code == E_COMM:
+            msg += " [" + lib().t3hip_comm_last_error().decode() + "]"
         super().__init__(msg)
 
 
@@ -96,6 +98,7 @@ def lib():
         L.t3hip_strerror.restype = C.c_char_p
         L.t3hip_last_hip_error.restype = C.c_char_p
         L.t3hip_version.restype = C.c_char_p
+        L.t3hip_comm_last_error.restype = C.c_char_p
         L.t3hip_encoded_words.restype = C.c_uint64
         L.t3hip_frame_record_scratch_bytes.restype = C.c_uint64
         _lib_handle = L
@@ -507,6 +510,34 @@ def index_assemble(records_bytes, first_payload_offset=0):
     n = buf.size // FRAME_RECORD_BYTES
     _chk(lib().t3hip_index_assemble(_vp(buf), C.c_uint64(n), C.c_uint64(first_payload_offset)), "t3hip_index_assemble")
     return [FrameRecord.from_buffer_copy(buf[i * FRAME_RECORD_BYTES:(i + 1) * FRAME_RECORD_BYTES].tobytes()) for i in range(n)]
+
+
+COMM_ID_BYTES = 128
+PAD_FRAME_IDX = 2**64 - 1
+
+
+def comm_unique_id():
+    """Rank 0: the 128-byte rendezvous id of a new RCCL communicator (ncclGetUniqueId); hand it to the other ranks."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _chk(lib().t3hip_comm_unique_id(buf), "t3hip_comm_unique_id")
+    return bytes(buf)
+
+
+class Comm:
+    """One RCCL communicator bound to this process's device (t3hip_comm_create after init()); the frame-index exchange
+    step runs on it: index_allgather = ncclAllGather of 96-byte frame records, asynchronous on `stream`."""
+
+    def __init__(self, unique_id, world, rank):
+        self.h = C.c_void_p(); self.world, self.rank = world, rank
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        _chk(lib().t3hip_comm_create(buf, C.c_int(world), C.c_int(rank), C.byref(self.h)), "t3hip_comm_create")
+
+    def index_allgather(self, d_local, n_local, d_all, stream=0):
+        _chk(lib().t3hip_index_allgather(self.h, C.c_void_p(d_local), C.c_uint64(n_local), C.c_void_p(d_all), C.c_void_p(stream)), "t3hip_index_allgather")
+
+    def destroy(self):
+        if self.h:
+            lib().t3hip_comm_destroy(self.h); self.h = C.c_void_p()
 
 
 class Event:

@@ -452,6 +452,7 @@ const char* t3hip_strerror(int c) {
         case T3_OK: return "ok"; case T3_E_NODEVICE: return "no usable gfx950 device (t3hip_init not done or failed)";
         case T3_E_HIP: return "HIP runtime error"; case T3_E_ARG: return "bad argument"; case T3_E_CAPACITY: return "output buffer too small";
         case T3_E_HEADER: return "superframe header did not decode (RS/CRC-12)"; case T3_E_RS: return "uncorrectable RS block";
+        case T3_E_COMM: return "RCCL unavailable or collective failed";
     }
     return "unknown";
 }

@@ -46,7 +46,7 @@ def _worker(rank, world, port, q):
     local[:] = np.frombuffer(bytes(pad), np.uint8)
     for i, f in enumerate(mine):
         local[i], _ = _frame_record(t3, orc, ol, f)
-    gathered = sf.gather_records(torch.from_numpy(local))
+    gathered = sf.gather_records_torch(torch.from_numpy(local))
     index = sf.assemble_index(gathered, first_payload_offset=64)
     q.put((rank, [(r.frame_idx, r.n_words, r.byte_offset, r.crc32, r.sym_sum, bytes(r.header_syms)) for r in index]))
     dist.barrier()

@@ -61,19 +61,44 @@ def test_dropin_caller_sequence(gpu, orc, tmp_path):
     assert out["t3v_bytes"] == len(want) and out["t3v_hash"] == ol.fnv_hex(np.frombuffer(want, np.uint8))
 
 
+def test_bench_self_launch_cpu():
+    """`python bench.py --gpus 2` from a bare shell (no launcher, no RANK in the environment) starts its own two ranks before
+    any GPU call; the probe mode stops each rank right after the gloo rendezvous, so this runs without a GPU."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["T3_BENCH_RANK_PROBE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = sorted(l for l in r.stdout.splitlines() if l.startswith("probe rank"))
+    assert lines == ["probe rank 0 of 2 sum 3", "probe rank 1 of 2 sum 3"]
+
+
 @pytest.mark.gpu
 def test_bench_two_rank_rehearsal(gpu):
-    """bench.py's N>1 control flow (rank-sharded frames, one all-gather of index records, max-over-ranks timing, the index
-    assertions) on one card: two ranks on cuda:0, collectives over gloo (T3_BENCH_REHEARSE_ONE_GPU=1).  The driver runs the
-    real thing over RCCL on a whole node; this keeps that path from rotting."""
-    import socket
+    """bench.py's N>1 control flow (self-launch from a bare command line, rank-sharded distinct frames, the untimed warm-up
+    exchange, one all-gather of index records, max-over-ranks timing, the index assertions) on one card: two ranks on cuda:0,
+    the exchange over gloo (T3_BENCH_REHEARSE_ONE_GPU=1: RCCL refuses two ranks on one device).  The driver runs the real
+    thing over RCCL on a whole node; test_comm_single_rank covers the RCCL entry points themselves."""
     import sys
-    with socket.socket() as sk:                       # a free rendezvous port
-        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
-    env = dict(os.environ, T3_BENCH_REHEARSE_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--settle-ms", "5"],
-                       capture_output=True, text=True, env=env, timeout=600)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["T3_BENCH_REHEARSE_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "1", "--settle-ms", "5", "--frames-per-rank", "2"],
+                       capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak" and line["value"] > 0 and "cpu_baseline" not in line
+    assert line["n_gpus"] == 2 and line["steps"] == 8 and line["scaling"] == "weak" and line["value"] > 0 and "cpu_baseline" not in line
+
+
+@pytest.mark.gpu
+def test_comm_single_rank(gpu):
+    """The library's RCCL entry points on real hardware (a communicator of one rank: unique id, ncclCommInitRank,
+    ncclAllGather of frame records on a stream, destroy)."""
+    import torch
+    t3 = gpu
+    comm = t3.Comm(t3.comm_unique_id(), 1, 0)
+    rec = torch.arange(3 * t3.FRAME_RECORD_BYTES, dtype=torch.int32).to(torch.uint8).reshape(3, -1).cuda()
+    out = torch.zeros_like(rec)
+    comm.index_allgather(rec.data_ptr(), 3, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out, rec)
+    comm.destroy()
