@@ -1,6 +1,7 @@
 // t3_api_decode.cpp — decode-side half of the C-ABI (include/t3hip.h): header parse on the host, body kernels
 // on the device, block-level decode, error injector, frame index record.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <stdlib.h>
@@ -30,8 +31,12 @@ FxTables* d_fxtab = nullptr;    // field tables of the fused FIXED decoder
 uint32_t* d_synd_lut[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t synd_lut_bytes[4] = {0, 0, 0, 0};   // per k index
 uint8_t* d_fma = nullptr;       // fma[x][y][a] = a + x y: one table read per multiply-accumulate of the corrector
 uint32_t* d_roots[4] = {nullptr, nullptr, nullptr, nullptr};   // per k index: the Chien search (OLD:611-623) of every locator, tabulated
+uint32_t* d_synd_afrag[4] = {nullptr, nullptr, nullptr, nullptr};   // per k index: A operand of the syndrome MFMA (t3_host.hpp build_mfma_syndrome)
+uint32_t* d_synd_T = nullptr;   // descramble + trit expansion table of the syndrome MFMA
+uint8_t* d_fx2_small = nullptr; // log / exp / inverse byte tables of the fused decoders
 
 int k_index(int k) { return k == 24 ? 0 : k == 22 ? 1 : k == 20 ? 2 : k == 18 ? 3 : -1; }
+DevDiv to_dev(FastDiv f) { return DevDiv{f.mul, f.sh, f.d}; }
 
 // Fused FIXED decode (t3_decode_fused.hip): uniform k, 1-D, no beacon.  Returns T3_OK after launching, or 1 if not applicable.
 std::mutex g_tab_mu;   // the lazily built device tables below are shared by every caller thread
@@ -66,6 +71,16 @@ int ensure_fx_tables(int k) {
         HIPCHK(hipMalloc((void**)&d_roots[ki], n * 4));
         HIPCHK(hipMemcpy(d_roots[ki], tbl.data(), n * 4, hipMemcpyHostToDevice));
     }
+    if (!d_synd_afrag[ki]) {
+        std::vector<uint32_t> af; build_mfma_syndrome(k, af);
+        HIPCHK(hipMalloc((void**)&d_synd_afrag[ki], af.size() * 4)); HIPCHK(hipMemcpy(d_synd_afrag[ki], af.data(), af.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (!d_synd_T) {
+        std::vector<uint32_t> img; build_syndrome_T(img);
+        HIPCHK(hipMalloc((void**)&d_synd_T, img.size() * 4)); HIPCHK(hipMemcpy(d_synd_T, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+        uint8_t sm[kFx2SmallBytes]; build_fx2_small(sm);
+        HIPCHK(hipMalloc((void**)&d_fx2_small, sizeof sm)); HIPCHK(hipMemcpy(d_fx2_small, sm, sizeof sm, hipMemcpyHostToDevice));
+    }
     if (!d_fma) {
         const Field& F = field();
         std::vector<uint8_t> t(19696, 0);
@@ -83,17 +98,19 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
     for (int b = 1; b < 9; ++b) if (L.band_k[b] != L.band_k[0]) return 1;
     const int k = L.band_k[0], ki = k_index(k);
     { const int rc = ensure_fx_tables(k); if (rc) return rc; }
-    DecFxArgs a; memset(&a, 0, sizeof a);
+    DecFx2Args a; memset(&a, 0, sizeof a);
     a.in = body; a.in_bytes = body_bytes; a.out = d_out; a.n_units = units; a.fail = d_fail; a.roots = d_roots[ki];
-    a.tab = d_fxtab; a.lut = d_synd_lut[ki]; a.lut_bytes = synd_lut_bytes[ki];
-    a.k = (uint32_t)k; a.nb = 52; a.TS = 9u * 52u * (uint32_t)k; a.n_sym = (uint32_t)L.n_sym; a.hdr_syms = hdr_syms;
+    a.tab = d_fxtab; a.ttab = d_synd_T; a.small = d_fx2_small; a.afrag = d_synd_afrag[ki];
+    a.k = (uint32_t)k; a.nb = 52; a.div_nb = to_dev(fastdiv(a.nb)); a.TS = 9u * 52u * (uint32_t)k; a.n_sym = (uint32_t)L.n_sym; a.hdr_syms = hdr_syms;
     uint64_t maxb = 0;
     for (int b = 0; b < 9; ++b) { a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b]; a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6); maxb = std::max<uint64_t>(maxb, L.band_blocks[b]); }
     a.n_tiles = (uint32_t)((maxb + a.nb - 1) / a.nb);
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
-    a.fma = d_fma; a.fma_off = (kFxLut + a.lut_bytes + 15u) & ~15u;
+    a.fma = d_fma; a.fma_off = (uint32_t)kFx2T + (uint32_t)kSyndTBytes;
     a.y_off = a.fma_off + 19696u;
-    a.o_off = (a.y_off + a.TS + 16u + 15u) & ~15u;
+    a.q_off = (a.y_off + a.TS + 16u + 15u) & ~15u;                              // queue: 512 x 8 bytes of syndromes, 512 x 2 of item numbers
+    a.af_off = a.q_off + 4096u + 1024u;                                         // the syndrome matrix (A operand of the MFMA)
+    a.o_off = a.af_off + 4096u;
     a.lds_bytes = a.o_off + (to_pixels ? 0u : (a.TS / 26u) * 27u) + 64u;      // pixels are stored straight from registers
     const void* fn = nullptr;
     switch (26 - k) {
@@ -110,12 +127,28 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
         it = occ.emplace(fn, std::max(1, o)).first;
     }
     const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(a.n_tiles, (uint32_t)(api_n_cu() * it->second)));
+#ifdef T3_DEC_STAMPS
+    static uint64_t* d_dbg = nullptr; static int calls = 0;
+    if (!d_dbg) HIPCHK(hipMalloc((void**)&d_dbg, 8 * 8 * 4096));
+    HIPCHK(hipMemsetAsync(d_dbg, 0, 8 * 8 * 4096, s));
+    a.dbg = d_dbg;
+#endif
     void* args[] = {(void*)&a};
     HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(512), args, a.lds_bytes, s));
+#ifdef T3_DEC_STAMPS
+    if (++calls == 8) {                                     // one report, after warm-up: mean cycles of wave 0 per workgroup and phase
+        std::vector<uint64_t> h(8 * grid);
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t w = 0; w < grid; ++w) for (int i = 0; i < 8; ++i) acc[i] += (double)h[8 * w + i];
+        fprintf(stderr, "[t3 dec stamps] grid=%u (%d per CU) tiles=%u lds=%u  mean cycles/WG: wait-input=%.0f sets+e1=%.0f barriers=%.0f bm=%.0f d5=%.0f total=%.0f  clock=%.3f GHz  us/WG=%.1f\n",
+                grid, it->second, a.n_tiles, a.lds_bytes, acc[0] / grid, acc[1] / grid, acc[2] / grid, acc[3] / grid, acc[4] / grid, acc[5] / grid, acc[5] / acc[6] * 0.1, acc[6] / grid * 0.01);
+    }
+#endif
     return T3_OK;
 }
 
-DevDiv to_dev(FastDiv f) { return DevDiv{f.mul, f.sh, f.d}; }
 unsigned grid_for(uint64_t items, unsigned block) { return (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, (items + block - 1) / block), 1u << 20); }
 
 int occupancy_of(const void* fn, int threads, uint32_t lds_bytes, int* out) {
@@ -280,7 +313,8 @@ void decode_shutdown() {
     std::lock_guard<std::mutex> lk(g_tab_mu);
     auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
     fr(d_zpow); fr(d_crc_acc); fr(d_crc_afrag); fr(d_fxtab); fr(d_fma);
-    for (int i = 0; i < 4; ++i) { fr(d_synd_lut[i]); synd_lut_bytes[i] = 0; fr(d_roots[i]); }
+    for (int i = 0; i < 4; ++i) { fr(d_synd_lut[i]); synd_lut_bytes[i] = 0; fr(d_roots[i]); fr(d_synd_afrag[i]); }
+    fr(d_synd_T); fr(d_fx2_small);
 }
 int decode_init(const RsTables*) {
     // Z[0]: one zero byte through the byte-wise register update; Z[j+1] = Z[j] o Z[j]

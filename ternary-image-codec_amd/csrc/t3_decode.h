@@ -74,6 +74,28 @@ struct DecFxArgs {
     uint32_t y_off, o_off, lds_bytes;
 };
 
+// Fused FIXED-mode decoder, second version (t3_decode_fused.hip): syndromes on the matrix cores (two lanes per block, T table =
+// descramble + trit expansion in one conflict-free read), single errors fixed in closed form by the lane that owns the block,
+// the remaining flagged blocks compacted (wave ballot) into an LDS queue and corrected by full waves.
+// LDS: [rows 0..144][queue counters 160,164][small tables 192][FxTables 512][T 3072][FMA][symbols Y][queue]
+constexpr int kFx2Cnt = 160, kFx2Small = 192, kFx2T = 3072;
+struct DecFx2Args {
+    const uint8_t* in; uint64_t in_bytes;      // whole coded stream
+    void* out; uint64_t n_units;               // pixels (to_pixels) or words to emit
+    uint32_t* fail;
+    const FxTables* tab; const uint32_t* ttab; const uint8_t* small; const uint32_t* afrag;   // device images (t3_host.hpp)
+    const uint8_t* fma; uint32_t fma_off;      // [27][27][27]: fma[x][y][a] = a + x y in GF(27) (19683 bytes), and its LDS offset
+    const uint32_t* roots;                     // [27^t]: bit i set <=> 1 + s1 x + .. + st x^t vanishes at alpha^-i, index s1 + 27 s2 + ..
+    uint32_t k, nb, n_tiles, TS;               // nb blocks per band per tile (multiple of 13), TS = 9*nb*k stream symbols
+    DevDiv div_nb;
+    uint32_t n_sym;                            // real stream symbols (the rest of the last blocks is zero padding)
+    uint32_t hdr_syms;
+    uint32_t band_blocks[9]; uint64_t band_body_off[9]; uint32_t band_boff6[9];
+    uint32_t cyc24, pre0, pre1;
+    uint32_t y_off, q_off, o_off, af_off, lds_bytes;
+    uint64_t* dbg;                             // diagnostic stamp builds only (T3_DEC_STAMPS); null in the product
+};
+
 // Two-kernel FIXED decoder for the framings the fully fused kernel does not take (mixed k, 2-D interleave; a beacon is
 // stripped by a pre-pass): D1-D4 as above with the bands grouped by k (whole waves per group), corrected data symbols to a
 // stream-ordered scratch; then symbols [through the de-interleave map] -> units.  (t3_decode_stream.hip)
@@ -107,7 +129,7 @@ void decode_shutdown();                       // frees what decode_init and the 
 
 #if defined(__HIPCC__)
 __global__ void dec_gather_rs_kernel(const DecArgs a);
-template <int R, bool TO_PIXELS> __global__ void decode_fixed_kernel(const DecFxArgs a);
+template <int R, bool TO_PIXELS> __global__ void decode_fixed_kernel(const DecFx2Args a);
 __global__ void decode_stream_kernel(const DecStArgs a);
 template <bool TO_PIXELS> __global__ void emit_stream_kernel(const EmitStArgs a);
 __global__ void debeacon_kernel(const DebeaconArgs a);

@@ -226,6 +226,46 @@ void build_syndrome_lut(int k, std::vector<uint32_t>& image) {
     }
 }
 
+void build_mfma_syndrome(int k, std::vector<uint32_t>& afrag) {
+    const Field& F = field(); RsView v = rs_view(F.t);
+    const int r = 26 - k, H = r / 2;
+    afrag.assign(4 * 64 * 4, 0u);
+    for (int s = 0; s < 4; ++s) for (int l = 0; l < 64; ++l) for (int d = 0; d < 4; ++d) {
+        const int m = l & 31, kh = l >> 5, hh = (m >> 2) & 1, i = (m & 3) + 4 * (m >> 3);
+        const int q = 4 * s + d;
+        if (q >= 13 || i >= 3 * H) continue;
+        const int p = 13 * kh + q, j = hh * H + i / 3, t = i % 3;
+        const uint8_t g = v.P((j + 1) * p);
+        uint32_t dw = 0;
+        for (int tt = 0; tt < 3; ++tt) {
+            const int e = tt == 0 ? 1 : tt == 1 ? 3 : 9;                      // the symbol whose only non-zero trit is tt
+            const int c = F.t.mul[e * 27 + g];
+            const int tr[3] = {c % 3, (c / 3) % 3, c / 9};
+            dw |= (uint32_t)(tr[t] == 2 ? 0xFFu : (uint32_t)tr[t]) << (tt == 2 ? 24 : 8 * tt);
+        }
+        afrag[(size_t)(s * 64 + l) * 4 + d] = dw;
+    }
+}
+void build_syndrome_T(std::vector<uint32_t>& img) {
+    const Field& F = field();
+    img.assign(kSyndTBytes / 4, 0u);
+    auto sb = [](int t) { return (uint32_t)(t == 2 ? 0xFF : t); };
+    for (int st = 0; st < 3; ++st) for (int c = 0; c < 27; ++c) {
+        const int d = F.t.add[c * 27 + F.t.neg[13 * st]];                      // c - (st,st,st) trit-wise (descramble_symbol OLD:88-94)
+        const uint32_t dw = sb(d % 3) | sb((d / 3) % 3) << 8 | (uint32_t)d << 16 | sb(d / 9) << 24;
+        for (int b = 0; b < 32; ++b) img[(size_t)st * kSyndTState / 4 + (size_t)c * 32 + b] = dw;
+    }
+}
+void build_fx2_small(uint8_t out[kFx2SmallBytes]) {
+    const Field& F = field();
+    memset(out, 0, kFx2SmallBytes);
+    for (int x = 0; x < 27; ++x) {
+        out[kFx2LG + x] = x ? (uint8_t)F.log[x] : 0xFF;
+        out[kFx2INV + x] = F.t.inv[x]; out[kFx2NEG + x] = F.t.neg[x]; out[kFx2NINV + x] = F.t.neg[F.t.inv[x]];
+    }
+    for (int i = 0; i < 26; ++i) out[kFx2EX + i] = F.t.exp[i];
+}
+
 // ---- scrambler ----------------------------------------------------------------------------------------
 ScrCycle scrambler_cycle_from_next(const uint8_t next[3], uint32_t s0) {
     ScrCycle c; memset(&c, 0, sizeof c);

@@ -73,6 +73,22 @@ void build_mfma_encode(int k, int mode, std::vector<uint32_t>& afrag, std::vecto
 int  syndrome_lut_slab(int k);
 void build_syndrome_lut(int k, std::vector<uint32_t>& image);
 
+// Tables of the matrix-core syndrome stage of the fused FIXED decoders (decoder v2).  Syndromes are GF(3)-linear in the
+// received trits: S_j = sum_p c_p alpha^{(j+1) p}, per block a 3r x 78 matrix-vector product mod 3, done by four
+// v_mfma_i32_32x32x32_i8 for 32 blocks (two lanes per block: lane half kh holds positions 13 kh .. 13 kh + 12).
+//   afrag : A operand, 4 K-steps x 64 lanes x 4 dwords: lane l = (row m = l&31, K-half kh = l>>5), dword d of step s = position
+//           p = 13 kh + 4 s + d (slots 4 s + d >= 13 are zero); bytes 0, 1, 3 = coefficient of trit 0, 1, 2 of that symbol
+//           (signed: 2 == -1), byte 2 = 0 (it meets the descrambled symbol).  Row m = accumulator register
+//           i = (m&3) + 4 (m>>3) of lane half hh = (m>>2)&1, which is trit i%3 of syndrome hh r/2 + i/3 (i < 3 r/2).
+//   T     : 3 scrambler states x 27 coded symbols x 32 bank copies (every lane reads its own bank), dword = trit0 | trit1<<8 |
+//           d<<16 | trit2<<24 of the DEscrambled symbol d = c - (s,s,s); at state * kSyndTState + (c * 32 + bank) * 4
+//   small : byte tables LG[27] (log, 0xFF for 0) | EX[26] | INV[27] | NEG[27] | NINV[27] (= -1/x) at kFx2* offsets
+constexpr int kSyndTState = 27 * 128, kSyndTBytes = 3 * kSyndTState;
+constexpr int kFx2LG = 0, kFx2EX = 32, kFx2INV = 64, kFx2NEG = 96, kFx2NINV = 128, kFx2SmallBytes = 160;
+void build_mfma_syndrome(int k, std::vector<uint32_t>& afrag);          // 4 * 64 * 4 dwords
+void build_syndrome_T(std::vector<uint32_t>& img);                      // kSyndTBytes / 4 dwords
+void build_fx2_small(uint8_t out[kFx2SmallBytes]);
+
 // ---- scrambler (OLD:77-94) ------------------------------------------------------------------------
 struct ScrCycle {
     uint8_t pre[2];      // state applied to body symbols 0 and 1
