@@ -32,7 +32,7 @@ uint32_t* d_synd_lut[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t synd_lu
 uint8_t* d_fma = nullptr;       // fma[x][y][a] = a + x y: one table read per multiply-accumulate of the corrector
 uint32_t* d_roots[4] = {nullptr, nullptr, nullptr, nullptr};   // per k index: the Chien search (OLD:611-623) of every locator, tabulated
 uint32_t* d_synd_afrag[4] = {nullptr, nullptr, nullptr, nullptr};   // per k index: A operand of the syndrome MFMA (t3_host.hpp build_mfma_syndrome)
-uint32_t* d_synd_T = nullptr;   // descramble + trit expansion table of the syndrome MFMA
+uint32_t* d_synd_T = nullptr, *d_synd_T16 = nullptr;   // descramble + trit expansion table of the syndrome MFMA (32 / 16 bank copies)
 uint8_t* d_fx2_small = nullptr; // log / exp / inverse byte tables of the fused decoders
 
 int k_index(int k) { return k == 24 ? 0 : k == 22 ? 1 : k == 20 ? 2 : k == 18 ? 3 : -1; }
@@ -78,7 +78,9 @@ int ensure_fx_tables(int k) {
     if (!d_synd_T) {
         std::vector<uint32_t> img; build_syndrome_T(img);
         HIPCHK(hipMalloc((void**)&d_synd_T, img.size() * 4)); HIPCHK(hipMemcpy(d_synd_T, img.data(), img.size() * 4, hipMemcpyHostToDevice));
-        uint8_t sm[kFx2SmallBytes]; build_fx2_small(sm);
+        build_syndrome_T(img, 16);
+        HIPCHK(hipMalloc((void**)&d_synd_T16, img.size() * 4)); HIPCHK(hipMemcpy(d_synd_T16, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+        uint8_t sm[kFx2SmallBytes + kFx2ModBytes]; build_fx2_small(sm); build_fx2_mod(sm + kFx2SmallBytes);
         HIPCHK(hipMalloc((void**)&d_fx2_small, sizeof sm)); HIPCHK(hipMemcpy(d_fx2_small, sm, sizeof sm, hipMemcpyHostToDevice));
     }
     if (!d_fma) {
@@ -100,50 +102,69 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
     { const int rc = ensure_fx_tables(k); if (rc) return rc; }
     DecFx2Args a; memset(&a, 0, sizeof a);
     a.in = body; a.in_bytes = body_bytes; a.out = d_out; a.n_units = units; a.fail = d_fail; a.roots = d_roots[ki];
-    a.tab = d_fxtab; a.ttab = d_synd_T; a.small = d_fx2_small; a.afrag = d_synd_afrag[ki];
+    a.ttab = to_pixels ? d_synd_T16 : d_synd_T; a.small = d_fx2_small; a.afrag = d_synd_afrag[ki];
     a.k = (uint32_t)k; a.nb = 52; a.div_nb = to_dev(fastdiv(a.nb)); a.TS = 9u * 52u * (uint32_t)k; a.n_sym = (uint32_t)L.n_sym; a.hdr_syms = hdr_syms;
     uint64_t maxb = 0;
     for (int b = 0; b < 9; ++b) { a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b]; a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6); maxb = std::max<uint64_t>(maxb, L.band_blocks[b]); }
     a.n_tiles = (uint32_t)((maxb + a.nb - 1) / a.nb);
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
-    a.fma = d_fma; a.fma_off = (uint32_t)kFx2T + (uint32_t)kSyndTBytes;
-    a.y_off = a.fma_off + 19696u;
-    a.q_off = (a.y_off + a.TS + 16u + 15u) & ~15u;                              // queue: 512 x 8 bytes of syndromes, 512 x 2 of item numbers
-    a.af_off = a.q_off + 4096u + 1024u;                                         // the syndrome matrix (A operand of the MFMA)
-    a.o_off = a.af_off + 4096u;
-    a.lds_bytes = a.o_off + (to_pixels ? 0u : (a.TS / 26u) * 27u) + 64u;      // pixels are stored straight from registers
+    a.fma = d_fma;
+    const uint32_t ybytes = (a.TS + 16u + 15u) & ~15u;
+    if (to_pixels) {   // [hdr][fold 512][T16 1024][FMA][A operand][Y0][Y1][Q0][Q1]
+        a.fma_off = (uint32_t)kFx2TPx + 3u * 27u * 4u * 16u;
+        a.af_off = a.fma_off + 19696u;
+        a.y_off = a.af_off + 3328u; a.y_stride = ybytes;
+        a.q_off = a.y_off + 2u * ybytes; a.q_stride = 10u * (uint32_t)kFx2QCap;    // 8 bytes of syndromes + 2 of item number per entry
+        a.o_off = a.q_off + 2u * a.q_stride;
+        a.lds_bytes = a.o_off + 16u;                                                // <= 42 x 1280 B: LDS is handed out in 1280-byte units, 128 per CU (three workgroups)
+    } else {           // [hdr][fold 3072][T32 3584][FMA][A operand][Y][Q][words]
+        a.fma_off = (uint32_t)kFx2TSeq + 3u * 27u * 4u * 32u;
+        a.af_off = a.fma_off + 19696u;
+        a.y_off = a.af_off + 3328u; a.y_stride = 0;
+        a.q_off = a.y_off + ybytes; a.q_stride = 0;
+        a.o_off = a.q_off + 10u * 512u;
+        a.lds_bytes = a.o_off + (a.TS / 26u) * 27u + 64u;
+    }
     const void* fn = nullptr;
     switch (26 - k) {
-        case 2: fn = to_pixels ? (const void*)decode_fixed_kernel<2, true> : (const void*)decode_fixed_kernel<2, false>; break;
-        case 4: fn = to_pixels ? (const void*)decode_fixed_kernel<4, true> : (const void*)decode_fixed_kernel<4, false>; break;
-        case 6: fn = to_pixels ? (const void*)decode_fixed_kernel<6, true> : (const void*)decode_fixed_kernel<6, false>; break;
-        default: fn = to_pixels ? (const void*)decode_fixed_kernel<8, true> : (const void*)decode_fixed_kernel<8, false>; break;
+        case 2: fn = to_pixels ? (const void*)decode_fixed_px_kernel<2> : (const void*)decode_fixed_kernel<2>; break;
+        case 4: fn = to_pixels ? (const void*)decode_fixed_px_kernel<4> : (const void*)decode_fixed_kernel<4>; break;
+        case 6: fn = to_pixels ? (const void*)decode_fixed_px_kernel<6> : (const void*)decode_fixed_kernel<6>; break;
+        default: fn = to_pixels ? (const void*)decode_fixed_px_kernel<8> : (const void*)decode_fixed_kernel<8>; break;
     }
     static std::map<const void*, int> occ;
     auto it = occ.find(fn);
     if (it == occ.end()) {
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int o = 1; HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, 512, a.lds_bytes));
+        // measured on MI355X (stamp build, workgroup start times): LDS is handed out in 1280-byte units, 128 per CU; the occupancy
+        // query does not round, and a persistent grid sized one workgroup per CU too large runs its last third after the rest
+        o = std::min<int>(o, (int)(128u / ((a.lds_bytes + 1279u) / 1280u)));
         it = occ.emplace(fn, std::max(1, o)).first;
     }
     const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(a.n_tiles, (uint32_t)(api_n_cu() * it->second)));
 #ifdef T3_DEC_STAMPS
     static uint64_t* d_dbg = nullptr; static int calls = 0;
-    if (!d_dbg) HIPCHK(hipMalloc((void**)&d_dbg, 8 * 8 * 4096));
-    HIPCHK(hipMemsetAsync(d_dbg, 0, 8 * 8 * 4096, s));
+    if (!d_dbg) HIPCHK(hipMalloc((void**)&d_dbg, 16 * 8 * 4096));
+    HIPCHK(hipMemsetAsync(d_dbg, 0, 16 * 8 * 4096, s));
     a.dbg = d_dbg;
 #endif
     void* args[] = {(void*)&a};
     HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(512), args, a.lds_bytes, s));
 #ifdef T3_DEC_STAMPS
-    if (++calls == 8) {                                     // one report, after warm-up: mean cycles of wave 0 per workgroup and phase
-        std::vector<uint64_t> h(8 * grid);
+    if (++calls == 8 && to_pixels) {                        // one report, after warm-up: mean cycles of waves 0 / 4 per workgroup and phase
+        std::vector<uint64_t> h(16 * grid);
         HIPCHK(hipStreamSynchronize(s));
         HIPCHK(hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t w = 0; w < grid; ++w) for (int i = 0; i < 8; ++i) acc[i] += (double)h[8 * w + i];
-        fprintf(stderr, "[t3 dec stamps] grid=%u (%d per CU) tiles=%u lds=%u  mean cycles/WG: wait-input=%.0f sets+e1=%.0f barriers=%.0f bm=%.0f d5=%.0f total=%.0f  clock=%.3f GHz  us/WG=%.1f\n",
-                grid, it->second, a.n_tiles, a.lds_bytes, acc[0] / grid, acc[1] / grid, acc[2] / grid, acc[3] / grid, acc[4] / grid, acc[5] / grid, acc[5] / acc[6] * 0.1, acc[6] / grid * 0.01);
+        double acc[16] = {0};
+        for (uint32_t w = 0; w < grid; ++w) for (int i = 0; i < 16; ++i) acc[i] += (double)h[16 * w + i];
+        fprintf(stderr, "[t3 dec stamps] grid=%u (%d per CU) tiles=%u lds=%u  mean cycles/WG: producer sets+e1=%.0f barrier=%.0f total=%.0f | consumer bm=%.0f rendezvous=%.0f d5=%.0f barrier=%.0f total=%.0f  clock=%.3f GHz  us/WG=%.1f\n",
+                grid, it->second, a.n_tiles, a.lds_bytes, acc[0] / grid, acc[1] / grid, acc[6] / grid, acc[8 + 2] / grid, acc[8 + 3] / grid, acc[8 + 4] / grid, acc[8 + 5] / grid, acc[8 + 6] / grid,
+                acc[6] / acc[7] * 0.1, acc[7] / grid * 0.01);
+        uint64_t s0 = ~0ull, s1 = 0, e1 = 0; int late = 0;
+        for (uint32_t w = 0; w < grid; ++w) { s0 = std::min(s0, h[16 * w + 2]); s1 = std::max(s1, h[16 * w + 2]); e1 = std::max(e1, h[16 * w + 3]); }
+        for (uint32_t w = 0; w < grid; ++w) if (h[16 * w + 2] - s0 > 1000) ++late;
+        fprintf(stderr, "[t3 dec stamps]   timeline (us from first loop start): last start=%.1f last end=%.1f  workgroups starting >10 us late=%d\n", (s1 - s0) * 0.01, (e1 - s0) * 0.01, late);
     }
 #endif
     return T3_OK;
@@ -314,7 +335,7 @@ void decode_shutdown() {
     auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
     fr(d_zpow); fr(d_crc_acc); fr(d_crc_afrag); fr(d_fxtab); fr(d_fma);
     for (int i = 0; i < 4; ++i) { fr(d_synd_lut[i]); synd_lut_bytes[i] = 0; fr(d_roots[i]); fr(d_synd_afrag[i]); }
-    fr(d_synd_T); fr(d_fx2_small);
+    fr(d_synd_T); fr(d_synd_T16); fr(d_fx2_small);
 }
 int decode_init(const RsTables*) {
     // Z[0]: one zero byte through the byte-wise register update; Z[j+1] = Z[j] o Z[j]

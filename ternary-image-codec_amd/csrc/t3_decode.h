@@ -75,15 +75,21 @@ struct DecFxArgs {
 };
 
 // Fused FIXED-mode decoder, second version (t3_decode_fused.hip): syndromes on the matrix cores (two lanes per block, T table =
-// descramble + trit expansion in one conflict-free read), single errors fixed in closed form by the lane that owns the block,
-// the remaining flagged blocks compacted (wave ballot) into an LDS queue and corrected by full waves.
-// LDS: [rows 0..144][queue counters 160,164][small tables 192][FxTables 512][T 3072][FMA][symbols Y][queue]
-constexpr int kFx2Cnt = 160, kFx2Small = 192, kFx2T = 3072;
+// descramble + trit expansion in one read), single errors fixed in closed form by the lane that owns the block, the remaining
+// flagged blocks compacted (wave ballot) into an LDS queue and corrected by full waves.  Two kernels share the block stages:
+//   decode_fixed_px_kernel  (pixels out)  waves 0-3 produce (sets, single errors, queue) tile k while waves 4-7 consume
+//                           (queue -> Berlekamp-Massey, symbols -> pixels) tile k-1: double-buffered symbols and queues, one
+//                           workgroup barrier per tile.  LDS: [hdr 0][fold tables 512][T16 1024][FMA][A operand][Y0][Y1][Q0][Q1]
+//   decode_fixed_kernel     (raw words out) the phases run one after the other (sets | queue | words staged in LDS).
+//                           LDS: [hdr 0][fold tables 3072][T32 3584][FMA][A operand][Y][Q][words]
+// hdr: band rows 0..143, queue counters 160/164, consumer rendezvous 168, give-up flag 172, small byte tables 192, dummy 384..511
+constexpr int kFx2Cnt = 160, kFx2Sync = 168, kFx2Abort = 172, kFx2Small = 192;
+constexpr int kFx2ModSeq = 3072, kFx2TSeq = 3584, kFx2ModPx = 512, kFx2TPx = 1024, kFx2QCap = 256;
 struct DecFx2Args {
     const uint8_t* in; uint64_t in_bytes;      // whole coded stream
-    void* out; uint64_t n_units;               // pixels (to_pixels) or words to emit
+    void* out; uint64_t n_units;               // pixels or words to emit
     uint32_t* fail;
-    const FxTables* tab; const uint32_t* ttab; const uint8_t* small; const uint32_t* afrag;   // device images (t3_host.hpp)
+    const uint32_t* ttab; const uint8_t* small; const uint32_t* afrag;   // device images (t3_host.hpp): T (32 or 16 copies), [byte tables][fold tables], A operand
     const uint8_t* fma; uint32_t fma_off;      // [27][27][27]: fma[x][y][a] = a + x y in GF(27) (19683 bytes), and its LDS offset
     const uint32_t* roots;                     // [27^t]: bit i set <=> 1 + s1 x + .. + st x^t vanishes at alpha^-i, index s1 + 27 s2 + ..
     uint32_t k, nb, n_tiles, TS;               // nb blocks per band per tile (multiple of 13), TS = 9*nb*k stream symbols
@@ -92,7 +98,7 @@ struct DecFx2Args {
     uint32_t hdr_syms;
     uint32_t band_blocks[9]; uint64_t band_body_off[9]; uint32_t band_boff6[9];
     uint32_t cyc24, pre0, pre1;
-    uint32_t y_off, q_off, o_off, af_off, lds_bytes;
+    uint32_t y_off, y_stride, q_off, q_stride, o_off, af_off, lds_bytes;   // px kernel: two symbol buffers / queues, y_stride / q_stride apart
     uint64_t* dbg;                             // diagnostic stamp builds only (T3_DEC_STAMPS); null in the product
 };
 
@@ -129,7 +135,8 @@ void decode_shutdown();                       // frees what decode_init and the 
 
 #if defined(__HIPCC__)
 __global__ void dec_gather_rs_kernel(const DecArgs a);
-template <int R, bool TO_PIXELS> __global__ void decode_fixed_kernel(const DecFx2Args a);
+template <int R> __global__ void decode_fixed_kernel(const DecFx2Args a);
+template <int R> __global__ void decode_fixed_px_kernel(const DecFx2Args a);
 __global__ void decode_stream_kernel(const DecStArgs a);
 template <bool TO_PIXELS> __global__ void emit_stream_kernel(const EmitStArgs a);
 __global__ void debeacon_kernel(const DebeaconArgs a);

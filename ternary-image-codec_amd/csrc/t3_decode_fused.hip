@@ -4,17 +4,23 @@
 // decode_block OLD:546-662 with the Forney sign fixed), the i%9 re-merge the reference omits, symbols -> 26-trit words
 // (OLD:1022-1040) and unpack_two_pixels (OLD:706-722).  Everything else goes through t3_decode_stream.hip / t3_decode.hip.
 //
-// Per tile (9 bands x nb blocks, eight waves):
-//   S   a wave takes two sets of 32 blocks, two lanes per block (t3_decode_fx2.h): one 16-byte load per lane, one conflict-free
-//       T-table read per coded symbol (descramble + trit expansion), syndromes on the matrix cores (78 x 3r GF(3) product as four
-//       v_mfma_i32_32x32x32_i8), mod-3 fold in the VALU, data symbols -> stream order in LDS (byte 9(mk+p)+b)
-//   E1  one lane = one block: non-zero syndromes that form a geometric progression are a single error, fixed in place
-//       (two logarithm reads and one patch); the other flagged blocks are appended to an LDS queue, one wave-aggregated
-//       counter update per wave (ballot + prefix count)
-//   BM  after a barrier full waves drain the queue: Berlekamp-Massey on a fused multiply-add table (a + x y, 27^3 bytes in LDS),
-//       Chien search by table (root mask per locator, global memory), Forney, <= t bytes patched
+// Stages of a tile (9 bands x nb blocks; block stages in t3_decode_fx2.h):
+//   S   a set = 32 blocks, two lanes per block: one 16-byte load per lane, one T-table read per coded symbol (descramble +
+//       trit expansion), syndromes on the matrix cores (78 x 3r GF(3) product as four v_mfma_i32_32x32x32_i8), mod-3 fold by
+//       byte tables, data symbols -> stream order in LDS (byte 9(mk+p)+b)
+//   E1  one lane = one block: non-zero syndromes that form a geometric progression are a single error, fixed in place; the
+//       other flagged blocks are appended to an LDS queue, one wave-aggregated counter update per wave (ballot + prefix count)
+//   BM  full waves drain the queue: Berlekamp-Massey on a fused multiply-add table (a + x y, 27^3 bytes in LDS), Chien search
+//       by table (root mask per locator, global memory), Forney, <= t bytes patched
 //   D5  pixels: one lane = four triples, 13 aligned dwords of symbols -> 12 pixels with packed 16-bit ops -> 72 bytes stored
 //       straight to memory;  raw words: 26 symbols -> 3 words, staged in LDS, copied out with 16-byte coalesced stores.
+//
+// decode_fixed_px_kernel (pixels): every stage is a chain of dependent LDS reads (the correction alone is ~35 levels), so a
+// workgroup that runs them one after the other spends most of a tile waiting.  Waves 0-3 (producers) therefore run S + E1 of tile
+// k while waves 4-7 (consumers) run BM + D5 of tile k-1 on the other symbol buffer / queue: one workgroup barrier per tile, a
+// four-wave rendezvous (LDS counter) between BM and D5.  The producers issue no stores and the consumers no streaming loads,
+// so the input loads (issued one pass ahead) never wait behind store acknowledgements.
+// decode_fixed_kernel (raw words): the same stages one after the other.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,175 +33,254 @@ namespace t3 {
 
 namespace {
 __device__ __forceinline__ void barrier_lds2() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// A tile's input is fetched one tile ahead into registers (plain loads, issued right after the previous tile's sets).  vmcnt
-// completes in order and stores count too, so the loads are WAITED FOR before this tile's pixel stores are issued (an empty
-// asm statement that names the registers makes the compiler place its s_waitcnt there): the wait then covers loads that have
-// had the whole correction phase to land, not the acknowledgement of stores issued a moment ago.
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(2))) V4a2 { v4u32 v; };
 __device__ __forceinline__ v4u32 load16(const uint8_t* p) { return ((const V4a2*)p)->v; }
+__device__ __forceinline__ uint32_t mod3u(uint32_t x) { return x - 3u * (uint32_t)(((uint64_t)x * 0xAAAAAAABull) >> 33); }
+
+// constants -> LDS (both kernels): band rows, counters, byte tables, fold tables, T, multiply-accumulate table, A operand
+template <uint32_t TCOP, uint32_t TBASE, uint32_t MT>
+__device__ __forceinline__ void stage_tables(const DecFx2Args& a, const uint32_t tid, const uint32_t nthr) {
+    if (tid == 0) {
+#pragma unroll
+        for (int b = 0; b < 9; ++b) { Row r; r.blocks = a.band_blocks[b]; r.boff6 = a.band_boff6[b]; r.body_off = a.band_body_off[b]; *(Row*)(lds + 16 * b) = r; }
+        *(uint32_t*)(lds + kFx2Cnt) = 0; *(uint32_t*)(lds + kFx2Cnt + 4) = 0; *(uint32_t*)(lds + kFx2Sync) = 0; *(uint32_t*)(lds + kFx2Abort) = 0;
+    }
+    for (uint32_t i = tid * 16u; i < (uint32_t)kFx2SmallBytes; i += nthr * 16u) *(uint4*)(lds + kFx2Small + i) = *(const uint4*)(a.small + i);
+    for (uint32_t i = tid * 16u; i < (uint32_t)kFx2ModBytes; i += nthr * 16u) *(uint4*)(lds + MT + i) = *(const uint4*)(a.small + kFx2SmallBytes + i);
+    for (uint32_t i = tid * 16u; i < 3u * 27u * 4u * TCOP; i += nthr * 16u) *(uint4*)(lds + TBASE + i) = *(const uint4*)((const uint8_t*)a.ttab + i);
+    for (uint32_t i = tid * 16u; i < 19696u; i += nthr * 16u) *(uint4*)(lds + a.fma_off + i) = *(const uint4*)(a.fma + i);
+    for (uint32_t i = tid * 16u; i < 3072u; i += nthr * 16u) *(uint4*)(lds + a.af_off + i) = *(const uint4*)((const uint8_t*)a.afrag + i);
+    if (tid < 64u) *(uint32_t*)(lds + a.af_off + 3072u + 4u * tid) = a.afrag[(3u * 64u + tid) * 4u];       // step 3: dword 0 of every lane
 }
+
+// E1 for the 64 blocks two sets leave with a wave (lower half-wave: set A, upper: set B): single errors fixed in place, the other
+// flagged blocks appended to the queue at q_off (syndromes, 8 bytes; item numbers, 2 bytes, behind qcap entries); a block that
+// finds the queue full is corrected on the spot.
+template <int R>
+__device__ __forceinline__ void fx2_own_blocks(const DecFx2Args& a, const Synd& sA, const Synd& sB, const Blk& bA, const Blk& bB, const uint32_t item,
+                                               const uint32_t lane, const uint32_t cnt_addr, const uint32_t q_off, const uint32_t qcap) {
+    const uint32_t h = lane >> 5;
+    Synd own; own.lo = h ? sB.lo : sA.lo; own.hi = h ? sB.hi : sA.hi;
+    const bool valid = h ? bB.valid : bA.valid;
+    const uint32_t yb = h ? bB.yb : bA.yb;
+    bool flagged = valid && (own.lo | own.hi) != 0u;                                // OLD:562: all-zero syndromes -> nothing to do
+    if (flagged) flagged = fx2_single<R>(own, yb, a.fma_off) == 0u;
+    const uint64_t bal = __builtin_amdgcn_ballot_w64(flagged);
+    if (bal != 0ull) {                                                              // wave-aggregated append: one LDS atomic per wave
+        const uint32_t cnt = (uint32_t)__popcll(bal), first = (uint32_t)__builtin_ctzll(bal);
+        uint32_t base = 0;
+        if (lane == first) base = __hip_atomic_fetch_add((uint32_t*)__builtin_assume_aligned(lds + cnt_addr, 4), cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = __builtin_amdgcn_readlane(base, (int)first);
+        if (flagged) {
+            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (__builtin_expect(slot < qcap, 1)) {
+                *T3_LP(u32x2, q_off + 8u * slot) = u32x2{own.lo, own.hi};              // the r syndromes ...
+                *T3_LP(uint16_t, q_off + 8u * qcap + 2u * slot) = (uint16_t)item;      // ... and the block's item number (< 512)
+            } else if (!fx2_fix_block<R>(own.lo, own.hi, yb, a.roots, a.fma_off)) atomicAdd(a.fail, 1u);   // queue full (cold)
+        }
+    }
+}
+
+// BM for queue entry e: the block's symbols are at y_off + band + 9 K (block within the tile)
+template <int R>
+__device__ __forceinline__ void fx2_queue_entry(const DecFx2Args& a, const uint32_t e, const uint32_t q_off, const uint32_t qcap, const uint32_t y_off) {
+    constexpr uint32_t K = 26 - R;
+    const u32x2 sy = *T3_LP(const u32x2, q_off + 8u * e);
+    const uint32_t item = *T3_LP(const uint16_t, q_off + 8u * qcap + 2u * e);
+    const uint32_t bi = min(__umulhi(item, a.div_nb.mul) >> a.div_nb.sh, 8u), m = item - bi * a.nb;
+    if (!fx2_fix_block<R>(sy.x, sy.y, y_off + bi + 9u * K * m, a.roots, a.fma_off)) atomicAdd(a.fail, 1u);
+}
+
+// D5 (pixels) for lane slot j of a tile: four triples = 52 symbols at y_off + 52 j -> 12 pixels = 72 bytes
+__device__ __forceinline__ void fx2_pixels12(const DecFx2Args& a, const uint32_t j, const uint32_t y_off, const uint64_t unit0, const uint32_t n_here) {
+    uint32_t D[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) D[i] = *T3_LP(const uint32_t, y_off + 52u * j + 4u * i);
+    uint32_t o[18];
+    px12_from_syms(D, o);
+    uint8_t* g = (uint8_t*)a.out + (unit0 + 12ull * j) * 6u;                        // 8-byte aligned
+    if (12u * j + 12u <= n_here) {
+        typedef uint32_t v4u __attribute__((ext_vector_type(4), aligned(8)));
+        typedef uint32_t v2u __attribute__((ext_vector_type(2), aligned(8)));
+#pragma unroll
+        for (int d = 0; d < 4; ++d) *(v4u*)(g + 16 * d) = v4u{o[4 * d], o[4 * d + 1], o[4 * d + 2], o[4 * d + 3]};
+        *(v2u*)(g + 64) = v2u{o[16], o[17]};
+    } else {                                                                        // the frame's last pixels: per 16-bit component
+#pragma unroll
+        for (uint32_t hh = 0; hh < 36; ++hh)
+            if (12u * j + hh / 3u < n_here) *(uint16_t*)(g + 2u * hh) = (uint16_t)(o[hh >> 1] >> (16u * (hh & 1u)));
+    }
+}
+}  // namespace
 
 #ifndef T3_DEC_WAVES_PER_EU
 #define T3_DEC_WAVES_PER_EU 6   // <= 80 VGPRs: three 8-wave workgroups per CU
 #endif
-#ifdef T3_DEC_STAMPS   // diagnostic build: per-phase cycle sums of wave 0 (never in the product build)
+#ifdef T3_DEC_STAMPS   // diagnostic build: per-phase cycle sums of waves 0 and 4 (never in the product build)
 #define T3D_STAMP(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
 #else
 #define T3D_STAMP(i) do { } while (0)
 #endif
-template <int R, bool TO_PIXELS>
-__global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_kernel(const DecFx2Args a) {
-    constexpr uint32_t K = 26 - R, H = R / 2;
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // constants -> LDS
-    if (tid == 0) {
-#pragma unroll
-        for (int b = 0; b < 9; ++b) { Row r; r.blocks = a.band_blocks[b]; r.boff6 = a.band_boff6[b]; r.body_off = a.band_body_off[b]; *(Row*)(lds + 16 * b) = r; }
-        *(uint32_t*)(lds + kFx2Cnt) = 0; *(uint32_t*)(lds + kFx2Cnt + 4) = 0;
-    }
-    for (uint32_t i = tid * 16u; i < (uint32_t)kFx2SmallBytes; i += nthr * 16u) *(uint4*)(lds + kFx2Small + i) = *(const uint4*)(a.small + i);
-    for (uint32_t i = tid * 16u; i < (uint32_t)sizeof(FxTables); i += nthr * 16u) *(uint4*)(lds + kFxTab + i) = *(const uint4*)((const uint8_t*)a.tab + i);
-    for (uint32_t i = tid * 16u; i < (uint32_t)kSyndTBytes; i += nthr * 16u) *(uint4*)(lds + kFx2T + i) = *(const uint4*)((const uint8_t*)a.ttab + i);
-    for (uint32_t i = tid * 16u; i < 19696u; i += nthr * 16u) *(uint4*)(lds + a.fma_off + i) = *(const uint4*)(a.fma + i);
-    for (uint32_t i = tid * 16u; i < 4096u; i += nthr * 16u) *(uint4*)(lds + a.af_off + i) = *(const uint4*)((const uint8_t*)a.afrag + i);
+
+// ------------------------------------------------------------------------------------------------------------------
+// pixels out: producer / consumer waves
+// ------------------------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_px_kernel(const DecFx2Args a) {
+    constexpr uint32_t TCOP = 16, TBASE = kFx2TPx, MT = kFx2ModPx, QCAP = kFx2QCap;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    stage_tables<TCOP, TBASE, MT>(a, tid, blockDim.x);
     __syncthreads();
 #ifdef T3_DEC_STAMPS
     uint64_t st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime(), st_t0 = st_prev, st_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-
     const uint8_t* body = a.in + a.hdr_syms;
-    const uint32_t n_items = 9u * a.nb;
-    const uint32_t units_tile = TO_PIXELS ? (a.TS / 13u) * 3u : (a.TS / 26u) * 3u;       // pixels / words produced per tile
-    const uint32_t n = lane & 31u, h = lane >> 5;
-    // lanes without a block read the first bytes of the body (always there) and ignore them
-    auto src_of = [&](const Blk& b) -> const uint8_t* { return b.valid ? b.g + 10u * h : body; };
-    v4u32 PA = {0, 0, 0, 0}, PB = {0, 0, 0, 0};                                    // this wave's two sets of the current tile, prefetched
-    if (blockIdx.x < a.n_tiles) {
-        PA = load16(src_of(fx2_block_of<R>(wave * 64u + n, n_items, a.nb, a.div_nb, blockIdx.x, body, a.y_off)));
-        PB = load16(src_of(fx2_block_of<R>(wave * 64u + 32u + n, n_items, a.nb, a.div_nb, blockIdx.x, body, a.y_off)));
-    }
-    uint32_t par = 0;
-    for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x, par ^= 1u) {
-        // ---------------- S: two sets of 32 blocks per wave ----------------
-        const Blk bA = fx2_block_of<R>(wave * 64u + n, n_items, a.nb, a.div_nb, tile, body, a.y_off);
-        const Blk bB = fx2_block_of<R>(wave * 64u + 32u + n, n_items, a.nb, a.div_nb, tile, body, a.y_off);
-        T3D_STAMP(0);
-        const uint32_t LA[4] = {PA[0], PA[1], PA[2], PA[3]}, LB[4] = {PB[0], PB[1], PB[2], PB[3]};
-        const Synd sA = fx2_set<R>(bA, LA, lane, a.af_off, a.cyc24, a.pre0, a.pre1);
-        const Synd sB = fx2_set<R>(bB, LB, lane, a.af_off, a.cyc24, a.pre0, a.pre1);
-        {   // the next tile's input, in flight under this tile's correction phase
-            const uint32_t nt = tile + gridDim.x;
-            if (nt < a.n_tiles) {
-                PA = load16(src_of(fx2_block_of<R>(wave * 64u + n, n_items, a.nb, a.div_nb, nt, body, a.y_off)));
-                PB = load16(src_of(fx2_block_of<R>(wave * 64u + 32u + n, n_items, a.nb, a.div_nb, nt, body, a.y_off)));
-            }
-        }
-        // ---------------- E1: one lane = one block (lower half-wave: set A, upper: set B) ----------------
-        {
-            Synd own; own.lo = h ? sB.lo : sA.lo; own.hi = h ? sB.hi : sA.hi;
-            const bool valid = h ? bB.valid : bA.valid;
-            const uint32_t yb = h ? bB.yb : bA.yb;
-            bool flagged = valid && (own.lo | own.hi) != 0u;                        // OLD:562: all-zero syndromes -> nothing to do
-            if (flagged) flagged = fx2_single<R>(own, yb, a.fma_off) == 0u;
-            const uint64_t bal = __builtin_amdgcn_ballot_w64(flagged);
-            if (bal != 0ull) {                                                      // wave-aggregated append: one LDS atomic per wave
-                const uint32_t cnt = (uint32_t)__popcll(bal);
-                uint32_t base = 0;
-                if (lane == 0) base = __hip_atomic_fetch_add((uint32_t*)__builtin_assume_aligned(lds + kFx2Cnt + 4u * par, 4), cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (flagged) {
-                    const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    *T3_LP(u32x2, a.q_off + 8u * slot) = u32x2{own.lo, own.hi};         // the r syndromes ...
-                    *T3_LP(uint16_t, a.q_off + 4096u + 2u * slot) = (uint16_t)(wave * 64u + lane);   // ... and the block's item number (< 512)
+    const uint32_t n_items = 9u * a.nb, grid = gridDim.x;
+    const uint32_t n_my = blockIdx.x < a.n_tiles ? (a.n_tiles - blockIdx.x + grid - 1u) / grid : 0u;    // tiles of this workgroup
+    const uint32_t units_tile = (a.TS / 13u) * 3u;                                  // pixels per tile
+
+    if (wave < 4u) {
+        // ---------------- producers: S + E1, two passes of two sets per tile and wave ----------------
+        const uint32_t n = lane & 31u, h = lane >> 5;
+        // one packed register of tile-independent geometry per (pass, set); made opaque inside the loop, or the compiler unpacks all
+        // four ahead of it and spills the pieces (80-VGPR budget)
+        Geo geo[2][2];
+#pragma unroll
+        for (uint32_t p = 0; p < 2; ++p) for (uint32_t q = 0; q < 2; ++q) geo[p][q] = fx2_geo(wave * 128u + p * 64u + q * 32u + n, n_items, a.nb, a.div_nb);
+        auto blk = [&](uint32_t pass, uint32_t set, uint32_t tile, uint32_t y_off) -> Blk {
+            const uint32_t tb = tile * a.nb;
+            Geo g = geo[pass][set]; asm volatile("" : "+v"(g));
+            return fx2_block<R>(g, tb, mod3u(tb), y_off);
+        };
+        // lanes without a block read the first bytes of the body (always there) and ignore them
+        auto src_of = [&](const Blk& b) -> const uint8_t* { return body + (b.valid ? b.off + 10u * h : 0u); };
+        v4u32 PA = {0, 0, 0, 0}, PB = {0, 0, 0, 0};                                // the next pass's two sets, in flight
+        if (n_my) { PA = load16(src_of(blk(0, 0, blockIdx.x, 0))); PB = load16(src_of(blk(0, 1, blockIdx.x, 0))); }
+        for (uint32_t k = 0; k < n_my; ++k) {
+            const uint32_t tile = blockIdx.x + k * grid, buf = k & 1u;
+            const uint32_t y_off = a.y_off + buf * a.y_stride, q_off = a.q_off + buf * a.q_stride;
+#pragma unroll
+            for (uint32_t pass = 0; pass < 2; ++pass) {
+                const uint32_t LA[4] = {PA[0], PA[1], PA[2], PA[3]}, LB[4] = {PB[0], PB[1], PB[2], PB[3]};
+                {   // the next pass's input: in flight under this pass (the producers issue no stores, so it is waited for alone)
+                    const uint32_t np = pass ^ 1u, nt = pass == 0 ? tile : tile + grid;
+                    if (nt < a.n_tiles) { PA = load16(src_of(blk(np, 0, nt, 0))); PB = load16(src_of(blk(np, 1, nt, 0))); }
                 }
+                if (wave * 128u + pass * 64u >= n_items) continue;                   // (wave-uniform) nothing left of the tile for this pass
+                const Blk bA = blk(pass, 0, tile, y_off), bB = blk(pass, 1, tile, y_off);
+                const Synd sA = fx2_set<R, TCOP, TBASE, MT>(bA, LA, lane, a.af_off, a.cyc24, a.pre0, a.pre1);
+                Synd sB; sB.lo = 0; sB.hi = 0;
+                if (wave * 128u + pass * 64u + 32u < n_items) sB = fx2_set<R, TCOP, TBASE, MT>(bB, LB, lane, a.af_off, a.cyc24, a.pre0, a.pre1);
+                fx2_own_blocks<R>(a, sA, sB, bA, bB, wave * 128u + pass * 64u + lane, lane, kFx2Cnt + 4u * buf, q_off, QCAP);
             }
+            T3D_STAMP(0);
+            barrier_lds2();
+            T3D_STAMP(1);
         }
-        T3D_STAMP(1);
-        barrier_lds2();
-        T3D_STAMP(2);
-        // ---------------- BM: full waves drain the queue ----------------
-        {
-            const uint32_t Q = *(const uint32_t*)(lds + kFx2Cnt + 4u * par);
-            for (uint32_t e0 = wave * 64u; e0 < Q; e0 += nthr) {
-                const uint32_t e = e0 + lane;
-                if (e < Q) {
-                    const u32x2 sy = *T3_LP(const u32x2, a.q_off + 8u * e);
-                    const uint32_t item = *T3_LP(const uint16_t, a.q_off + 4096u + 2u * e);
-                    uint32_t S[R];
-#pragma unroll
-                    for (uint32_t j = 0; j < (uint32_t)R; ++j) S[j] = ((j < H ? sy.x : sy.y) >> (8u * (j % H))) & 0xFFu;
-                    const uint32_t bi = min(__umulhi(item, a.div_nb.mul) >> a.div_nb.sh, 8u), m = item - bi * a.nb;
-                    const uint32_t yb = a.y_off + bi + 9u * K * m;
-                    Fix fx; fx.np = 0;
-                    uint32_t rc = fx2_correct<R>(S, fx, a.roots, a.fma_off);
-                    if (rc == 2u) rc = fx_correct<R>(S, fx, a.roots, a.fma_off) ? 0u : 1u;   // longer register than t: the full-length routine decides
-                    if (rc != 0u) atomicAdd(a.fail, 1u);
-                    else {
-#pragma unroll
-                        for (int q = 0; q < R / 2; ++q)
-                            if ((uint32_t)q < fx.np && fx.pos[q] < K) { const uint32_t ad = yb + 9u * fx.pos[q]; *T3_LP(uint8_t, ad) = (uint8_t)l8(a.fma_off + (54u + fx.mag[q]) * 27u + l8(ad)); }
+        barrier_lds2();                                                             // the consumers' last interval
+    } else {
+        // ---------------- consumers: BM + D5 of the tile the producers finished in the previous interval ----------------
+        const uint32_t cw = wave - 4u;
+        for (uint32_t k = 0; k <= n_my; ++k) {
+            if (k >= 1u) {
+                const uint32_t tile = blockIdx.x + (k - 1u) * grid, buf = (k - 1u) & 1u;
+                const uint32_t y_off = a.y_off + buf * a.y_stride, q_off = a.q_off + buf * a.q_stride;
+                const uint32_t Q = min(*(const uint32_t*)(lds + kFx2Cnt + 4u * buf), QCAP);
+                for (uint32_t e0 = cw * 64u; e0 < Q; e0 += 256u) { const uint32_t e = e0 + lane; if (e < Q) fx2_queue_entry<R>(a, e, q_off, QCAP, y_off); }
+                T3D_STAMP(2);
+                // rendezvous of the four consumer waves: every patch is in LDS before any wave converts symbols
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                uint32_t* const sync = (uint32_t*)__builtin_assume_aligned(lds + kFx2Sync, 4);
+                if (lane == 0) __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                {
+                    uint32_t spins = 0;
+                    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * k) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 22)) { if (lane == 0) { *(uint32_t*)(lds + kFx2Abort) = 1u; atomicAdd(a.fail, 1u << 20); } break; }   // never seen; a bound, not a path
                     }
                 }
+                if (tid == 256u) *(uint32_t*)(lds + kFx2Cnt + 4u * buf) = 0;         // every consumer has read Q; the producers touch this counter after the barrier
+                T3D_STAMP(3);
+                const uint64_t unit0 = (uint64_t)tile * units_tile;
+                const uint32_t n_here = (uint32_t)min((uint64_t)units_tile, a.n_units > unit0 ? a.n_units - unit0 : 0ull);
+                for (uint32_t j = cw * 64u + lane; 4u * j < a.TS / 13u; j += 256u) fx2_pixels12(a, j, y_off, unit0, n_here);
+                T3D_STAMP(4);
             }
-            if (tid == 0) *(uint32_t*)(lds + kFx2Cnt + 4u * (par ^ 1u)) = 0;        // the next tile's counter (nobody touches it in this phase)
+            barrier_lds2();
+            T3D_STAMP(5);
         }
-        T3D_STAMP(3);
-        barrier_lds2();
-        T3D_STAMP(2);
-        asm volatile("" : "+v"(PA), "+v"(PB));                                     // the next tile's input has landed (see load16)
-        // ---------------- D5: symbols -> output units ----------------
-        const uint64_t unit0 = (uint64_t)tile * units_tile;
-        const uint32_t n_here = (uint32_t)min((uint64_t)units_tile, a.n_units > unit0 ? a.n_units - unit0 : 0ull);
-        if constexpr (TO_PIXELS) {
-            // One lane = four consecutive triples: 52 symbols (13 aligned dwords of Y) -> 12 pixels = 72 bytes, stored straight
-            // to memory (lanes are consecutive, so a wave writes one contiguous run).  Triples 0/2 and 1/3 share registers as
-            // 16-bit halves; inverse of the encoder's splice (unpack_two_pixels OLD:706-722) in packed arithmetic.
-            const uint32_t ntr = a.TS / 13u;                                       // triples in the tile (a multiple of 4, at most 4 * 512)
-            const uint32_t j = tid;
-            if (4u * j < ntr) {
-                uint32_t D[13];
-#pragma unroll
-                for (int i = 0; i < 13; ++i) D[i] = *T3_LP(const uint32_t, a.y_off + 52u * j + 4u * i);
-                uint32_t o[18];
-                px12_from_syms(D, o);
-                uint8_t* g = (uint8_t*)a.out + (unit0 + 12ull * j) * 6u;            // 8-byte aligned
-                const bool whole = 12u * j + 12u <= n_here;
-                if (whole) {
-                    typedef uint32_t v4u __attribute__((ext_vector_type(4), aligned(8)));
-                    typedef uint32_t v2u __attribute__((ext_vector_type(2), aligned(8)));
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) *(v4u*)(g + 16 * d) = v4u{o[4 * d], o[4 * d + 1], o[4 * d + 2], o[4 * d + 3]};
-                    *(v2u*)(g + 64) = v2u{o[16], o[17]};
-                } else {                                                            // the frame's last pixels: per 16-bit component
-#pragma unroll
-                    for (uint32_t hh = 0; hh < 36; ++hh)
-                        if (12u * j + hh / 3u < n_here) *(uint16_t*)(g + 2u * hh) = (uint16_t)(o[hh >> 1] >> (16u * (hh & 1u)));
-                }
-            }
-        } else {
-            const uint32_t ng = a.TS / 26u;                                        // groups of 26 symbols -> 3 words (OLD:1022-1040)
-            for (uint32_t j = tid; j < ng; j += nthr) words3_from_syms(a.y_off + 26u * j, a.o_off + 27u * j);
-            __syncthreads();
-            copy_out_lds((uint8_t*)a.out + unit0 * 9u, a.o_off, n_here * 9u, tid, nthr);   // tile starts are only 8-byte aligned
-        }
-        T3D_STAMP(4);
-        barrier_lds2();
-        T3D_STAMP(2);
     }
 #ifdef T3_DEC_STAMPS
-    if (tid == 0 && a.dbg) {
-        uint64_t* d = a.dbg + 8ull * blockIdx.x;
-        d[0] = st_acc[0]; d[1] = st_acc[1]; d[2] = st_acc[2]; d[3] = st_acc[3]; d[4] = st_acc[4];
-        d[5] = __builtin_amdgcn_s_memtime() - st_t0; d[6] = __builtin_amdgcn_s_memrealtime() - st_rt0;
+    if ((tid == 0 || tid == 256) && a.dbg) {
+        uint64_t* d = a.dbg + 16ull * blockIdx.x + (tid ? 8 : 0);
+        for (int i = 0; i < 6; ++i) d[i] = st_acc[i];
+        d[6] = __builtin_amdgcn_s_memtime() - st_t0; d[7] = __builtin_amdgcn_s_memrealtime() - st_rt0;
+        if (tid == 0) { d[2] = st_rt0; d[3] = __builtin_amdgcn_s_memrealtime(); }     // producer slots 2, 3: start / end on the 100 MHz clock
     }
 #endif
 }
 
-template __global__ void decode_fixed_kernel<2, true>(const DecFx2Args);  template __global__ void decode_fixed_kernel<2, false>(const DecFx2Args);
-template __global__ void decode_fixed_kernel<4, true>(const DecFx2Args);  template __global__ void decode_fixed_kernel<4, false>(const DecFx2Args);
-template __global__ void decode_fixed_kernel<6, true>(const DecFx2Args);  template __global__ void decode_fixed_kernel<6, false>(const DecFx2Args);
-template __global__ void decode_fixed_kernel<8, true>(const DecFx2Args);  template __global__ void decode_fixed_kernel<8, false>(const DecFx2Args);
+// ------------------------------------------------------------------------------------------------------------------
+// raw words out: the phases one after the other
+// ------------------------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_kernel(const DecFx2Args a) {
+    constexpr uint32_t TCOP = 32, TBASE = kFx2TSeq, MT = kFx2ModSeq;
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    stage_tables<TCOP, TBASE, MT>(a, tid, nthr);
+    __syncthreads();
+    const uint8_t* body = a.in + a.hdr_syms;
+    const uint32_t n_items = 9u * a.nb;
+    const uint32_t units_tile = (a.TS / 26u) * 3u;                                  // words per tile
+    const uint32_t n = lane & 31u, h = lane >> 5;
+    const Geo gA0 = fx2_geo(wave * 64u + n, n_items, a.nb, a.div_nb), gB0 = fx2_geo(wave * 64u + 32u + n, n_items, a.nb, a.div_nb);
+    Geo gA = gA0, gB = gB0;
+    auto src_of = [&](const Blk& b) -> const uint8_t* { return body + (b.valid ? b.off + 10u * h : 0u); };
+    v4u32 PA = {0, 0, 0, 0}, PB = {0, 0, 0, 0};                                    // this wave's two sets of the current tile, prefetched
+    if (blockIdx.x < a.n_tiles) {
+        PA = load16(src_of(fx2_block<R>(gA, blockIdx.x * a.nb, mod3u(blockIdx.x * a.nb), a.y_off)));
+        PB = load16(src_of(fx2_block<R>(gB, blockIdx.x * a.nb, mod3u(blockIdx.x * a.nb), a.y_off)));
+    }
+    uint32_t par = 0;
+    for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x, par ^= 1u) {
+        const uint32_t tb = tile * a.nb, t3 = mod3u(tb);
+        asm volatile("" : "+v"(gA), "+v"(gB));                                     // opaque: keeps the unpacked pieces out of loop-long registers
+        const Blk bA = fx2_block<R>(gA, tb, t3, a.y_off), bB = fx2_block<R>(gB, tb, t3, a.y_off);
+        const uint32_t LA[4] = {PA[0], PA[1], PA[2], PA[3]}, LB[4] = {PB[0], PB[1], PB[2], PB[3]};
+        const Synd sA = fx2_set<R, TCOP, TBASE, MT>(bA, LA, lane, a.af_off, a.cyc24, a.pre0, a.pre1);
+        const Synd sB = fx2_set<R, TCOP, TBASE, MT>(bB, LB, lane, a.af_off, a.cyc24, a.pre0, a.pre1);
+        {   // the next tile's input, in flight under this tile's correction phase
+            const uint32_t nt = tile + gridDim.x;
+            if (nt < a.n_tiles) {
+                PA = load16(src_of(fx2_block<R>(gA, nt * a.nb, mod3u(nt * a.nb), a.y_off)));
+                PB = load16(src_of(fx2_block<R>(gB, nt * a.nb, mod3u(nt * a.nb), a.y_off)));
+            }
+        }
+        fx2_own_blocks<R>(a, sA, sB, bA, bB, wave * 64u + lane, lane, kFx2Cnt + 4u * par, a.q_off, 512u);
+        barrier_lds2();
+        {
+            const uint32_t Q = *(const uint32_t*)(lds + kFx2Cnt + 4u * par);
+            for (uint32_t e0 = wave * 64u; e0 < Q; e0 += nthr) { const uint32_t e = e0 + lane; if (e < Q) fx2_queue_entry<R>(a, e, a.q_off, 512u, a.y_off); }
+            if (tid == 0) *(uint32_t*)(lds + kFx2Cnt + 4u * (par ^ 1u)) = 0;        // the next tile's counter (nobody touches it in this phase)
+        }
+        barrier_lds2();
+        // the loads are waited for BEFORE this tile's stores are issued (vmcnt completes in order, stores count too): they have had
+        // the correction phase to land, and the wait does not cover the acknowledgement of stores issued a moment ago
+        asm volatile("" : "+v"(PA), "+v"(PB));
+        const uint64_t unit0 = (uint64_t)tile * units_tile;
+        const uint32_t n_here = (uint32_t)min((uint64_t)units_tile, a.n_units > unit0 ? a.n_units - unit0 : 0ull);
+        const uint32_t ng = a.TS / 26u;                                            // groups of 26 symbols -> 3 words (OLD:1022-1040)
+        for (uint32_t j = tid; j < ng; j += nthr) words3_from_syms(a.y_off + 26u * j, a.o_off + 27u * j);
+        __syncthreads();
+        copy_out_lds((uint8_t*)a.out + unit0 * 9u, a.o_off, n_here * 9u, tid, nthr);   // tile starts are only 8-byte aligned
+        barrier_lds2();
+    }
+}
+
+template __global__ void decode_fixed_kernel<2>(const DecFx2Args);  template __global__ void decode_fixed_px_kernel<2>(const DecFx2Args);
+template __global__ void decode_fixed_kernel<4>(const DecFx2Args);  template __global__ void decode_fixed_px_kernel<4>(const DecFx2Args);
+template __global__ void decode_fixed_kernel<6>(const DecFx2Args);  template __global__ void decode_fixed_px_kernel<6>(const DecFx2Args);
+template __global__ void decode_fixed_kernel<8>(const DecFx2Args);  template __global__ void decode_fixed_px_kernel<8>(const DecFx2Args);
 
 }  // namespace t3

@@ -25,30 +25,43 @@ __device__ __forceinline__ uint32_t mod26(uint32_t u) { return min(u, u + 26u); 
 // What a set leaves with the two lanes of a block: the r syndromes, h = 0 half (S_0 .. S_{r/2-1}, one byte each) and h = 1 half
 struct Synd { uint32_t lo, hi; };
 
-// geometry of one block seen by its two lanes
-struct Blk { bool valid, first; uint32_t c0; const uint8_t* g; uint32_t yb; };
+// geometry of one block seen by its two lanes.  Geo is the tile-independent part (item -> band index, block within the tile).
+// One register per (lane, set): m | bi << 12 | m mod 3 << 16 | has-an-item << 18.
+typedef uint32_t Geo;
+struct Blk { bool valid, first; uint32_t c0, off, yb; };            // off: byte offset of the block from the body's first symbol
+constexpr uint32_t kFx2Dummy = 384;                                   // 128 bytes of LDS that take the writes of lanes without a block
 
+__device__ __forceinline__ Geo fx2_geo(const uint32_t item, const uint32_t n_items, const uint32_t nb, const DevDiv& div_nb) {
+    const uint32_t bi = min(__umulhi(item, div_nb.mul) >> div_nb.sh, 8u), m = item - bi * nb;       // nb >= 2
+    const uint32_t m3 = m - 3u * ((m * 683u) >> 11);                                                // m < 2048
+    return m | bi << 12 | m3 << 16 | (item < n_items ? 1u << 18 : 0u);
+}
+// tb = tile * nb and t3 = tb mod 3 are wave-uniform
 template <int R>
-__device__ __forceinline__ Blk fx2_block_of(const uint32_t item, const uint32_t n_items, const uint32_t nb, const DevDiv& div_nb, const uint32_t tile,
-                                            const uint8_t* body /* in + hdr_syms */, const uint32_t y_off) {
+__device__ __forceinline__ Blk fx2_block(const Geo g, const uint32_t tb, const uint32_t t3, const uint32_t y_off) {
     constexpr uint32_t K = 26 - R;
-    const uint32_t bi = min(__umulhi(item, div_nb.mul) >> div_nb.sh, 8u), m = item - bi * nb;     // nb >= 2
+    const uint32_t gm = g & 0xFFFu, bi = (g >> 12) & 15u, gm3 = (g >> 16) & 3u;
     const Row rw = row(bi);
-    const uint64_t mg = (uint64_t)tile * nb + m;
+    const uint32_t mg = tb + gm, boff = (uint32_t)rw.body_off;            // the coded stream is shorter than 4 GiB (t3_api_decode.cpp)
     Blk b;
-    b.valid = item < n_items && mg < rw.blocks;
-    b.first = rw.body_off == 0 && mg == 0;
-    b.c0 = (rw.boff6 + 2u * (uint32_t)(mg % 3u)) % 6u;                     // 26 == 2 (mod 6)
-    b.g = body + rw.body_off + 26ull * mg;
-    b.yb = y_off + bi + 9u * K * m;
+    b.valid = (g >> 18) != 0u && mg < rw.blocks;
+    b.first = boff == 0u && mg == 0u;
+    uint32_t s3 = gm3 + t3; s3 -= s3 >= 3u ? 3u : 0u;                    // mg mod 3
+    uint32_t c0 = rw.boff6 + 2u * s3; c0 -= c0 >= 6u ? 6u : 0u;          // 26 == 2 (mod 6)
+    b.c0 = c0;
+    b.off = boff + 26u * mg;
+    b.yb = y_off + bi + 9u * K * gm;
     return b;
 }
 
 // One set: lane (n, h) = half h of block `item0 + n`.  `Lw` = the lane's 16 coded bytes (block bytes [10 h, 10 h + 16)), loaded by
-// the caller (prefetched one tile ahead).
-template <int R>
+// the caller (prefetched ahead).  The three mod-3 fold tables M_t[x] = 3^t ((x - 81) mod 3) are 160 B each.
+// TCOP bank copies of the T table at LDS offset TBASE (32: conflict-free; 16: lanes n and n + 16 share a copy, two-way conflicts,
+// half the space); MT: LDS offset of the fold tables (a compile-time constant, so that it rides in the instruction's offset field).
+template <int R, uint32_t TCOP, uint32_t TBASE, uint32_t MT>
 __device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], const uint32_t lane, const uint32_t af_off,
                                         const uint32_t cyc24, const uint32_t pre0, const uint32_t pre1) {
+    constexpr uint32_t TSTATE = 27u * 4u * TCOP, mt = MT;
     constexpr uint32_t K = 26 - R, H = R / 2;
     const uint32_t n = lane & 31u, h = lane >> 5;
     // symbol q of this lane (position 13 h + q) = byte q of W: h = 1 starts at byte 3 of its load
@@ -72,42 +85,47 @@ __device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], c
     // scrambler state of position 13 h + q: cyc[(c0 + 13 h + q) mod 6], 13 == 1 (mod 6)
     uint32_t c0h = b.c0 + h; c0h -= c0h >= 6u ? 6u : 0u;
     const uint32_t cycs = cyc24 >> (2u * c0h);
+    const uint32_t tb0 = TBASE + 4u * (n % TCOP);
     uint32_t vb[6];                                                               // T base per position class: state, own bank copy
 #pragma unroll
-    for (uint32_t q = 0; q < 6; ++q) vb[q] = ((cycs >> (2u * q)) & 3u) * (uint32_t)kSyndTState + ((uint32_t)kFx2T + 4u * n);
+    for (uint32_t q = 0; q < 6; ++q) vb[q] = __umul24((cycs >> (2u * q)) & 3u, TSTATE) + tb0;
     const bool fst = b.first && h == 0;                                            // body symbols 0 and 1 see the pre-period states
-    const uint32_t vb0 = fst ? pre0 * (uint32_t)kSyndTState + ((uint32_t)kFx2T + 4u * n) : vb[0];
-    const uint32_t vb1 = fst ? pre1 * (uint32_t)kSyndTState + ((uint32_t)kFx2T + 4u * n) : vb[1];
-    const uint32_t ya = b.yb + 117u * h;                                           // 9 * 13
+    const uint32_t vb0 = fst ? pre0 * TSTATE + tb0 : vb[0];
+    const uint32_t vb1 = fst ? pre1 * TSTATE + tb0 : vb[1];
+    // data symbols -> stream order (byte 2 of a T entry = the descrambled symbol): h = 0 holds positions 0..12, h = 1 13..25, of
+    // which K..25 are parity; lanes without a block write into a dummy area instead of being masked off store by store
+    const uint32_t ya = b.valid ? b.yb + 117u * h : kFx2Dummy;                     // 9 * 13
     v16i_ acc = {81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81};     // bias: trit sums in [-78, 78] -> [3, 159]
 #pragma unroll
     for (uint32_t st = 0; st < 4; ++st) {
         v4i_ Bv = {0, 0, 0, 0};
+        uint32_t xs[4] = {0, 0, 0, 0};
 #pragma unroll
         for (uint32_t d = 0; d < 4; ++d) {
             const uint32_t q = 4u * st + d;
             if (q >= 13u) continue;
             const uint32_t c = (W[st] >> (8u * d)) & 0xFFu;
             const uint32_t base = q == 0 ? vb0 : q == 1 ? vb1 : vb[q % 6u];
-            const uint32_t x = *T3_LP(const uint32_t, (c << 7) + base);
-            Bv[d] = (int)x;
-            // data symbols -> stream order (byte 2 of the entry = the descrambled symbol): h = 0 holds positions 0..12, h = 1 13..25
-            if (b.valid && (h == 0 || q + 13u < K)) *T3_LP(uint8_t, ya + 9u * q) = (uint8_t)(x >> 16);
+            const uint32_t x = *T3_LP(const uint32_t, c * (4u * TCOP) + base);
+            Bv[d] = (int)x; xs[d] = x;
+            if (q + 13u < K) *T3_LP(uint8_t, ya + 9u * q) = (uint8_t)(x >> 16);   // both halves hold data here
         }
-        const v4i_ Af = *T3_LP(const v4i_, af_off + 16u * (64u * st + lane));        // the syndrome matrix lives in LDS (80-VGPR budget)
+        if (4u * st + 3u + 13u >= K) {                                              // positions >= K - 13 of the upper half are parity: one masked region per step
+            if (h == 0) {
+#pragma unroll
+                for (uint32_t d = 0; d < 4; ++d) { const uint32_t q = 4u * st + d; if (q < 13u && q + 13u >= K) *T3_LP(uint8_t, ya + 9u * q) = (uint8_t)(xs[d] >> 16); }
+            }
+        }
+        // the syndrome matrix lives in LDS (80-VGPR budget): three full steps, then step 3 of which only dword 0 (position 12) is used
+        v4i_ Af = {0, 0, 0, 0};
+        if (st < 3u) Af = *T3_LP(const v4i_, af_off + 16u * (64u * st + lane)); else Af[0] = *T3_LP(const int, af_off + 3072u + 4u * lane);
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af, Bv, acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);                                          // one K-step's table entries live at a time (80-VGPR budget)
     }
     uint32_t Pown = 0;
 #pragma unroll
-    for (uint32_t jj = 0; jj < H; ++jj) {
-        uint32_t s = 0;
-#pragma unroll
-        for (uint32_t t = 0; t < 3; ++t) {
-            const uint32_t x = (uint32_t)acc[3 * jj + t];
-            const uint32_t r = x - 3u * (__umul24(x, 171u) >> 9);                    // x < 512
-            s += r * (t == 0 ? 1u : t == 1 ? 3u : 9u);
-        }
+    for (uint32_t jj = 0; jj < H; ++jj) {                                          // mod-3 fold and 3^t weight by byte tables
+        const uint32_t s = l8(mt + (uint32_t)acc[3 * jj]) + l8(mt + 160u + (uint32_t)acc[3 * jj + 1]) + l8(mt + 320u + (uint32_t)acc[3 * jj + 2]);
         Pown |= s << (8u * jj);
     }
     const auto sw = __builtin_amdgcn_permlane32_swap(Pown, Pown, false, false);    // [0]: every lane sees the h = 0 half, [1]: the h = 1 half
@@ -140,32 +158,39 @@ __device__ __forceinline__ uint32_t fx2_single(const Synd& sy, const uint32_t yb
 
 // Berlekamp-Massey on T+1 coefficients + root table + short Omega.  Returns 0: corrected (fx filled), 1: uncorrectable,
 // 2: outside the short routine's conditions (the caller runs fx_correct on this lane).
+// Table index of a + x y = FMA + 729 x + 27 y + a; multiplication commutes, so the operand that is known early carries the
+// factor 729 (and the table base) and the other one the factor 27: one v_add3 per multiply-accumulate.
 template <int R>
 __device__ __forceinline__ uint32_t fx2_correct(const uint32_t* S, Fix& fx, const uint32_t* __restrict__ root_tbl, const uint32_t FMA) {
-    auto fma = [FMA](uint32_t acc, uint32_t x, uint32_t y) -> uint32_t { return l8(FMA + (x * 27u + y) * 27u + acc); };   // acc + x y
     constexpr int T = R / 2;
-    // sigma_1..T and x^m B as in fx_correct (B unscaled, the division kept in the scalar nbinv = -1 / d_old)
-    uint32_t sg[T + 1], bx[T + 1];
+    auto tab = [](uint32_t idx) -> uint32_t { return l8(idx); };
+    uint32_t Sx[R];                                                                // FMA + 729 S_j
 #pragma unroll
-    for (int i = 0; i <= T; ++i) { sg[i] = 0; bx[i] = 0; }
-    sg[0] = 1; bx[1] = 1;
-    uint32_t L = 0, nbinv = 2;                                                    // -1
+    for (int j = 0; j < R; ++j) Sx[j] = __umul24(S[j], 729u) + FMA;
+    // sigma_1..T (plain and x 27) and x^m B (x 27) as in fx_correct (B unscaled, the division kept in the scalar -1 / d_old)
+    uint32_t sg[T + 1], sg27[T + 1], bx27[T + 1];
+#pragma unroll
+    for (int i = 0; i <= T; ++i) { sg[i] = 0; sg27[i] = 0; bx27[i] = 0; }
+    sg[0] = 1; sg27[0] = 27; bx27[1] = 27;
+    uint32_t L = 0, nbx = FMA + 2u * 729u;                                        // FMA + 729 (-1 / d_old), d_old = 1
     bool over = false;
 #pragma unroll
     for (int n = 0; n < R; ++n) {
         uint32_t d = S[n];
 #pragma unroll
-        for (int i = 1; i <= T; ++i) if (i <= n) d = fma(d, sg[i], S[n - i]);
+        for (int i = 1; i <= T; ++i) if (i <= n) d = tab(Sx[n - i] + sg27[i] + d);   // d += sigma_i S_{n-i}
         const bool upd = d != 0 && 2u * L <= (uint32_t)n;
-        const uint32_t nc = fma(0u, d, nbinv);                                     // -(d / d_old)
-        uint32_t old[T + 1];
+        const uint32_t nc = tab(nbx + 27u * d);                                     // -(d / d_old)
+        const uint32_t ncx = __umul24(nc, 729u) + FMA;
+        uint32_t old27[T + 1];
 #pragma unroll
-        for (int i = 1; i <= T; ++i) { old[i] = sg[i]; if (i <= n + 1) sg[i] = fma(old[i], nc, bx[i]); }
-        old[0] = 1;
-        if (upd) { L = (uint32_t)n + 1u - L; nbinv = l8(SM + kFx2NINV + d); over = over || L > (uint32_t)T; }
+        for (int i = 0; i <= T; ++i) old27[i] = sg27[i];
 #pragma unroll
-        for (int i = T; i >= 1; --i) bx[i] = upd ? old[i - 1] : bx[i - 1];
-        bx[0] = 0;
+        for (int i = 1; i <= T; ++i) if (i <= n + 1) { sg[i] = tab(ncx + bx27[i] + sg[i]); sg27[i] = 27u * sg[i]; }   // sigma - (d / d_old) x^m B
+        if (upd) { L = (uint32_t)n + 1u - L; nbx = __umul24(l8(SM + kFx2NINV + d), 729u) + FMA; over = over || L > (uint32_t)T; }
+#pragma unroll
+        for (int i = T; i >= 1; --i) bx27[i] = upd ? old27[i - 1] : bx27[i - 1];
+        bx27[0] = 0;
     }
     uint32_t deg = 0;
 #pragma unroll
@@ -183,28 +208,111 @@ __device__ __forceinline__ uint32_t fx2_correct(const uint32_t* S, Fix& fx, cons
     for (int q = 0; q < T; ++q) {
         uint32_t acc = S[q];
 #pragma unroll
-        for (int j = 1; j <= q; ++j) acc = fma(acc, S[q - j], sg[j]);
+        for (int j = 1; j <= q; ++j) acc = tab(Sx[q - j] + sg27[j] + acc);
         Om[q] = acc;
     }
     uint32_t s22 = 0;                                                              // sigma' = sigma1 + 2 sigma2 x (+ sigma4 x^3)
-    if constexpr (T >= 2) s22 = fma(sg[2], 1u, sg[2]);
+    if constexpr (T >= 2) s22 = tab(FMA + 729u + sg27[2] + sg[2]);
+    const uint32_t s22_27 = 27u * s22;
     uint32_t r = roots;
 #pragma unroll
     for (int e = 0; e < T; ++e) {
         if ((uint32_t)e < np) {
             const uint32_t p = (uint32_t)__ffs((int)r) - 1u; r &= r - 1u;
             const uint32_t xi = l8(SM + kFx2EX + (p == 0 ? 0u : 26u - p));
+            const uint32_t xix = __umul24(xi, 729u) + FMA;
             uint32_t num = Om[T - 1];
 #pragma unroll
-            for (int q = T - 2; q >= 0; --q) num = fma(Om[q], num, xi);
-            uint32_t den = fma(sg[1], s22, xi);
-            if constexpr (T >= 4) den = fma(den, fma(0u, fma(0u, sg[4], xi), xi), xi);
+            for (int q = T - 2; q >= 0; --q) num = tab(xix + 27u * num + Om[q]);
+            uint32_t den = tab(xix + s22_27 + sg[1]);
+            if constexpr (T >= 4) { const uint32_t x2 = tab(xix + sg27[4]); const uint32_t x3 = tab(xix + 27u * x2); den = tab(xix + 27u * x3 + den); }
             if (den == 0) return 1u;                                                // OLD:656
-            fx.pos[e] = p; fx.mag[e] = fma(0u, l8(SM + kFx2NEG + num), l8(SM + kFx2INV + den));   // OLD:657; FIXED subtracts it
+            fx.pos[e] = p; fx.mag[e] = tab(FMA + 729u * l8(SM + kFx2NEG + num) + 27u * l8(SM + kFx2INV + den));   // OLD:657; FIXED subtracts it
         }
     }
     fx.np = np;
     return 0u;
+}
+
+// The full-length routine (fx_correct of t3_decode_fx.h: sigma on R + 2 coefficients, every Omega coefficient) with all of its
+// arithmetic on the multiply-accumulate table and the small byte tables, for the kernels that do not stage FxTables.
+template <int R>
+__device__ __forceinline__ bool fx2_correct_full(const uint32_t* S, Fix& fx, const uint32_t* __restrict__ root_tbl, const uint32_t FMA) {
+    auto fma = [FMA](uint32_t acc, uint32_t x, uint32_t y) -> uint32_t { return l8(FMA + (x * 27u + y) * 27u + acc); };   // acc + x y
+    constexpr int T = R / 2, NP = R + 2;
+    uint32_t sg[NP], bx[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { sg[i] = 0; bx[i] = 0; }
+    sg[0] = 1; bx[1] = 1;
+    uint32_t L = 0, nbinv = 2;
+#pragma unroll
+    for (int n = 0; n < R; ++n) {
+        uint32_t d = S[n];
+#pragma unroll
+        for (int i = 1; i <= n; ++i) d = fma(d, sg[i], S[n - i]);
+        const bool upd = d != 0 && 2u * L <= (uint32_t)n;
+        const uint32_t nc = fma(0u, d, nbinv);
+        uint32_t old[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) { old[i] = sg[i]; if (i <= n + 1) sg[i] = fma(old[i], nc, bx[i]); }
+        if (upd) { L = (uint32_t)n + 1u - L; nbinv = l8(SM + kFx2NINV + d); }
+#pragma unroll
+        for (int i = NP - 1; i >= 1; --i) bx[i] = upd ? old[i - 1] : bx[i - 1];
+        bx[0] = 0;
+    }
+    uint32_t deg = 0;
+#pragma unroll
+    for (int i = 1; i < NP; ++i) if (sg[i] != 0) deg = (uint32_t)i;
+    fx.np = 0;
+    if (deg > (uint32_t)T) return false;
+    uint32_t ridx = sg[T];
+#pragma unroll
+    for (int q = T - 1; q >= 1; --q) ridx = ridx * 27u + sg[q];
+    const uint32_t roots = root_tbl[ridx];
+    const uint32_t np = (uint32_t)__popc(roots);
+    if (np != deg) return false;
+    uint32_t Om[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        uint32_t acc = S[q];
+#pragma unroll
+        for (int j = 1; j <= T; ++j) if (j <= q) acc = fma(acc, S[q - j], sg[j]);
+        Om[q] = acc;
+    }
+    uint32_t r = roots;
+#pragma unroll
+    for (int e = 0; e < T; ++e) {
+        if ((uint32_t)e < np) {
+            const uint32_t p = (uint32_t)__ffs((int)r) - 1u; r &= r - 1u;
+            const uint32_t xi = l8(SM + kFx2EX + (p == 0 ? 0u : 26u - p));
+            uint32_t num = Om[R - 1];
+#pragma unroll
+            for (int q = R - 2; q >= 0; --q) num = fma(Om[q], num, xi);
+            uint32_t den = fma(sg[1], fma(sg[2], 1u, sg[2]), xi);
+            if constexpr (T >= 4) den = fma(den, fma(0u, fma(0u, sg[4], xi), xi), xi);
+            if (den == 0) return false;
+            fx.pos[e] = p; fx.mag[e] = fma(0u, l8(SM + kFx2NEG + num), l8(SM + kFx2INV + den));
+        }
+    }
+    fx.np = np;
+    return true;
+}
+
+// One queued block: syndromes -> corrections patched into the symbol buffer at yb; returns false for an uncorrectable block.
+template <int R>
+__device__ __forceinline__ bool fx2_fix_block(const uint32_t lo, const uint32_t hi, const uint32_t yb, const uint32_t* __restrict__ root_tbl, const uint32_t FMA) {
+    constexpr uint32_t K = 26 - R, H = R / 2;
+    uint32_t S[R];
+#pragma unroll
+    for (uint32_t j = 0; j < (uint32_t)R; ++j) S[j] = ((j < H ? lo : hi) >> (8u * (j % H))) & 0xFFu;
+    Fix fx; fx.np = 0;
+    uint32_t rc = fx2_correct<R>(S, fx, root_tbl, FMA);
+    if (rc == 2u) rc = fx2_correct_full<R>(S, fx, root_tbl, FMA) ? 0u : 1u;      // longer register than t: the full-length routine decides
+    if (rc != 0u) return false;
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q)
+        if ((uint32_t)q < fx.np && fx.pos[q] < K) { const uint32_t ad = yb + 9u * fx.pos[q]; *T3_LP(uint8_t, ad) = (uint8_t)l8(FMA + (54u + fx.mag[q]) * 27u + l8(ad)); }   // y - m = y + 2 m
+    return true;
 }
 
 }  // namespace

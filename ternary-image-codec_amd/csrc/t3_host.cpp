@@ -246,14 +246,14 @@ void build_mfma_syndrome(int k, std::vector<uint32_t>& afrag) {
         afrag[(size_t)(s * 64 + l) * 4 + d] = dw;
     }
 }
-void build_syndrome_T(std::vector<uint32_t>& img) {
+void build_syndrome_T(std::vector<uint32_t>& img, int copies) {
     const Field& F = field();
-    img.assign(kSyndTBytes / 4, 0u);
+    img.assign((size_t)3 * 27 * copies, 0u);
     auto sb = [](int t) { return (uint32_t)(t == 2 ? 0xFF : t); };
     for (int st = 0; st < 3; ++st) for (int c = 0; c < 27; ++c) {
         const int d = F.t.add[c * 27 + F.t.neg[13 * st]];                      // c - (st,st,st) trit-wise (descramble_symbol OLD:88-94)
         const uint32_t dw = sb(d % 3) | sb((d / 3) % 3) << 8 | (uint32_t)d << 16 | sb(d / 9) << 24;
-        for (int b = 0; b < 32; ++b) img[(size_t)st * kSyndTState / 4 + (size_t)c * 32 + b] = dw;
+        for (int b = 0; b < copies; ++b) img[((size_t)st * 27 + c) * copies + b] = dw;
     }
 }
 void build_fx2_small(uint8_t out[kFx2SmallBytes]) {
@@ -264,6 +264,9 @@ void build_fx2_small(uint8_t out[kFx2SmallBytes]) {
         out[kFx2INV + x] = F.t.inv[x]; out[kFx2NEG + x] = F.t.neg[x]; out[kFx2NINV + x] = F.t.neg[F.t.inv[x]];
     }
     for (int i = 0; i < 26; ++i) out[kFx2EX + i] = F.t.exp[i];
+}
+void build_fx2_mod(uint8_t out[kFx2ModBytes]) {
+    for (int t = 0; t < 3; ++t) for (int x = 0; x < 160; ++x) out[160 * t + x] = (uint8_t)((((x - 81) % 3 + 3) % 3) * (t == 0 ? 1 : t == 1 ? 3 : 9));
 }
 
 // ---- scrambler ----------------------------------------------------------------------------------------
