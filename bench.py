@@ -16,8 +16,9 @@ One step = one synthetic 8K (7680x4320) frame through the hot path on each rank,
      parsed on the host); the timed frames use the streaming entry t3hip_decode_frame_async: body decode launched with
      the configuration last seen, header symbols checked on the device, verdict words read inside the timed region
      after the last step (--sync-decode times the synchronous entry for every frame instead),
-  3. the frame's index record (CRC-32 + header symbols) for the T3V-style super-frame index; it depends only on step 1 and
-     runs on a second HIP stream under the decode (--serial puts it back on the main stream).
+  3. the frame's index record (CRC-32 + header symbols) for the T3V-style super-frame index, on the same stream
+     (--overlap-record: on a second HIP stream beside the decode, as in round 1; the round-2 decoder fills the register files,
+     so the CRC kernel then runs behind it anyway).
 Every rank holds --frames-per-rank (8) distinct frames, BASELINE configs[3]: global frame f = rank + N j has LCG seed
 12345 + f and lives on rank f mod N; step i works on the rank's frame i mod 8.  Frames are independent, so ranks shard them
 with no data-path collective (weak scaling); the only exchange is one all-gather of the K fixed-size index records per rank at
@@ -157,7 +158,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--encode-only", action="store_true", help="profiling aid: skip decode + index in the loop")
-    ap.add_argument("--serial", action="store_true", help="index record on the main stream instead of overlapping it with the decode")
+    ap.add_argument("--overlap-record", action="store_true", help="index record on a second HIP stream beside the decode (round 1's default; the round-2 decoder leaves the CRC kernel no registers to run beside it, so the record now follows on the main stream)")
+    ap.add_argument("--serial", action="store_true", help="(default now) index record on the main stream")
     ap.add_argument("--sync-decode", action="store_true", help="every frame through the synchronous decode entry (host-parsed header, two synchronisations per frame)")
     ap.add_argument("--no-verify", action="store_true", help="profiling aid for timing-only ablation builds (results are wrong by construction)")
     args = ap.parse_args()
@@ -201,8 +203,8 @@ def main():
     orc = ol.oracle()
     cur = torch.cuda.current_stream()
     stream = cur.cuda_stream
-    # the index record (CRC-32 of the coded frame) only depends on the encode: it runs on a second HIP stream under the decode
-    s2 = None if args.serial else torch.cuda.Stream(device=dev)
+    # the index record (CRC-32 of the coded frame) only depends on the encode; --overlap-record puts it on a second HIP stream
+    s2 = torch.cuda.Stream(device=dev) if (args.overlap_record and not args.serial) else None
     enc_done, rec_done = torch.cuda.Event(), torch.cuda.Event()
 
     # ---- synthetic input, resident in HBM before any timing (SURVEY §8d generator; global frame f has seed 12345 + f) ----

@@ -200,6 +200,27 @@ int t3hip_rs_encode_blocks_dev(int k, int mode, const uint8_t* d_data_k, uint64_
 int t3hip_rs_decode_blocks_dev(int k, int mode, uint8_t* d_code26, uint64_t n_blocks,
                                uint8_t* d_data_k, uint8_t* d_ok, void* stream);
 
+/* Host-buffer forms (what RSCodec::encode_block / decode_block of include/ternary_codec_v6.hpp bind): upload, the kernels above,
+ * download.  data_k of a block whose decode fails is returned as it came in (the reference leaves out_k untouched). */
+int t3hip_rs_encode_blocks(int k, int mode, const uint8_t* data_k, uint64_t n_blocks, uint8_t* code26);
+int t3hip_rs_decode_blocks(int k, int mode, uint8_t* code26_inout, uint64_t n_blocks, uint8_t* data_k, uint8_t* ok);
+
+/* ---- the reference's symbol-level public helpers --------------------------------------------------------
+ * Single symbols and the header are control data: host arithmetic on the tables the kernels are built from.
+ *   gf27_add / gf27_sub / gf27_mul_poly OLD:383-413 (operands reduced mod 27)
+ *   scramble_symbol / descramble_symbol OLD:81-94: *st <- (a * *st + b) % 3 in uint32 wrap-around, then every trit of s +/- *st
+ *   encode_beacon_symbol OLD:107-113;  CRC3::rem12 OLD:176-205 (ternary CRC-12 of n trits, 12 zero trits appended)
+ * interleave2D_boustrophedon / deinterleave2D_boustrophedon OLD:750-813 on a symbol vector: device kernel (the map is an
+ * involution inside every row segment, so `inverse` selects nothing); w == 0 or h == 0 leaves the symbols as they are. */
+uint8_t t3hip_gf27_add(uint8_t a, uint8_t b);
+uint8_t t3hip_gf27_sub(uint8_t a, uint8_t b);
+uint8_t t3hip_gf27_mul(uint8_t a, uint8_t b);
+uint8_t t3hip_scramble_symbol(uint8_t s, uint32_t a, uint32_t b, uint32_t* st, int inverse);
+uint8_t t3hip_beacon_symbol(uint8_t profile, uint16_t frame_seq_mod, uint8_t health_flags);
+int t3hip_crc12(const uint8_t* trits, uint64_t n, uint8_t out12[12]);
+int t3hip_interleave2d(uint8_t* syms, uint64_t n, uint16_t w, uint16_t h, int inverse);
+int t3hip_interleave2d_dev(const uint8_t* d_in, uint64_t n, uint16_t w, uint16_t h, uint8_t* d_out, void* stream);   /* d_out != d_in */
+
 /* ---- trit error injector for the recovery test ------------------ */
 /* For every 26-symbol block of the body region [first_sym, first_sym+26*n_blocks): a counter hash of
  * (seed, block) picks e in 0..max_err distinct positions and alters one trit of each. */

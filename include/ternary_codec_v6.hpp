@@ -12,9 +12,11 @@
 //   * encode_frame / decode_frame fuse pack+encode and decode+unpack into single launches (north-star conveniences).
 // Link with -lt3hip (ternary-image-codec_amd/libt3hip.so).
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <random>
 #include <vector>
 
 #include "t3hip.h"
@@ -43,7 +45,12 @@ inline void uep_uniform(UEPLayout& u, uint8_t idx = 1) { u.band_profile.fill(idx
 inline void uep_luma_priority(UEPLayout& u) { u.band_profile.fill(1); u.band_profile[0] = u.band_profile[3] = u.band_profile[6] = 2; }
 struct Tile2D { uint16_t w = 0, h = 0; };
 struct ScramblerSeed { uint32_t a = 1, b = 1, s0 = 1; };
+// one step of the stream scrambler on one symbol (OLD:81-94): the state is stepped first, in uint32 wrap-around arithmetic
+inline GF27 scramble_symbol(GF27 s, const ScramblerSeed& seed, uint32_t& st) { return t3hip_scramble_symbol(s, seed.a, seed.b, &st, 0); }
+inline GF27 descramble_symbol(GF27 s, const ScramblerSeed& seed, uint32_t& st) { return t3hip_scramble_symbol(s, seed.a, seed.b, &st, 1); }
 struct SparseBeaconCfg { uint32_t words_period = 0; uint8_t band_slot = 0; bool enabled = false; };
+struct BeaconPayload { ProfileID profile; uint16_t frame_seq_mod; uint8_t health_flags; };
+inline GF27 encode_beacon_symbol(const BeaconPayload& b) { return t3hip_beacon_symbol((uint8_t)b.profile, b.frame_seq_mod, b.health_flags); }   // OLD:107-113
 enum class CosetID : uint8_t { C0 = 0, C1 = 1, C2 = 2 };
 
 // ---- subword modes and centring (OLD:117-152) ---------------------------------------------------------------
@@ -104,6 +111,10 @@ struct SuperframeHeader {
     SparseBeaconCfg beacon{}; SubwordMode subword = SubwordMode::S27; bool centered = true; CosetID coset = CosetID::C0;
 };
 struct HeaderPack { std::array<GF27, 27> symbols{}; };
+struct CRC3 {   // OLD:176-205: ternary CRC-12, g = x^12 + x^7 + x^4 + x^3 + 1, twelve zero trits appended to the message
+    static constexpr int L = 12;
+    static inline void rem12(const std::vector<UTrit>& msg, std::array<UTrit, L>& out) { t3hip_crc12(msg.data(), msg.size(), out.data()); }
+};
 
 namespace t3 {
 inline int& status_slot() { static thread_local int s = T3_OK; return s; }
@@ -132,6 +143,46 @@ inline void from_pod(const t3_cfg& p, DecoderConfigSeen& c) {
 }
 }  // namespace t3
 
+// ---- GF(27) and the RS(26,k) block codec (OLD:383-663) ------------------------------------------------------------------
+inline GF27 gf27_add(GF27 a, GF27 b) { return t3hip_gf27_add(a, b); }
+inline GF27 gf27_sub(GF27 a, GF27 b) { return t3hip_gf27_sub(a, b); }
+inline GF27 gf27_mul_poly(GF27 a, GF27 b) { return t3hip_gf27_mul(a, b); }
+struct GF27Tables {
+    std::array<GF27, 26 * 3> exp{}; std::array<int16_t, 27> log{}; std::array<GF27, 27 * 27> mul{}; std::array<GF27, 27> inv{};
+    GF27 primitive = 0;
+};
+struct GF27Context {
+    GF27Tables tab{};
+    int order_of(GF27 g) const { if (g == 0 || g == 1) return -1; GF27 x = 1; for (int i = 1; i <= 26; ++i) { x = gf27_mul_poly(x, g); if (x == 1) return i; } return -1; }
+    void init() { t3hip_gf27_tables(tab.exp.data(), tab.log.data(), tab.mul.data(), tab.inv.data()); tab.primitive = tab.exp[1]; }   // OLD:436-466 (primitive = 3)
+    GF27 add(GF27 a, GF27 b) const { return gf27_add(a, b); }
+    GF27 sub(GF27 a, GF27 b) const { return gf27_sub(a, b); }
+    GF27 mul(GF27 a, GF27 b) const { return tab.mul[a * 27 + b]; }
+    GF27 inv(GF27 a) const { return tab.inv[a]; }
+    GF27 pow_alpha(int e) const { return tab.exp[(e % 26 + 26) % 26]; }
+    int log(GF27 a) const { return tab.log[a]; }
+};
+// One block per call through the block-level kernels (t3hip_rs_encode_blocks / t3hip_rs_decode_blocks): the reference's shape, fine
+// for its self-test and for header-sized work; whole frames go through encode_profile_from_raw / decode_profile_to_raw.
+// `mode` is build-side: T3_MODE_COMPAT = the reference's arithmetic (its parity map, Forney with add), T3_MODE_FIXED = v6c.
+struct RSCodec {
+    GF27Context* gf = nullptr; RSParams params{}; std::vector<GF27> g; uint8_t mode = T3_MODE_COMPAT;
+    void init(GF27Context* c, RSParams p) { gf = c; params = p; build_gen(); }
+    void build_gen() { g.assign((size_t)(params.n - params.k + 1), 0); if (t3hip_rs_generator(params.k, g.data()) != T3_OK) g.assign(1, 1); }   // OLD:501-516
+    bool encode_block(const GF27* data_k, GF27* out_n) const { return t3hip_rs_encode_blocks(params.k, mode, data_k, 1, out_n) == T3_OK; }   // OLD:517-535
+    GF27 poly_eval(const std::vector<GF27>& p, GF27 x) const {   // OLD:536-545 (Horner)
+        GF27 acc = 0;
+        for (int i = (int)p.size() - 1; i >= 0; --i) acc = gf27_add(gf27_mul_poly(acc, x), p[(size_t)i]);
+        return acc;
+    }
+    bool decode_block(GF27* inout_n, GF27* out_k) const {        // OLD:546-662: inout_n corrected in place, out_k only on success
+        uint8_t good = 0;
+        std::vector<GF27> keep(out_k, out_k + params.k);
+        if (t3hip_rs_decode_blocks(params.k, mode, inout_n, 1, out_k, &good) != T3_OK) { std::copy(keep.begin(), keep.end(), out_k); return false; }
+        return good != 0;
+    }
+};
+
 struct HeaderCodec {
     static HeaderPack pack(const SuperframeHeader& h) {
         EncoderConfig c; c.profile = h.profile; c.uep = h.uep; c.tile = h.tile; c.seed = h.seed; c.beacon = h.beacon;
@@ -151,6 +202,23 @@ struct HeaderCodec {
         return h;
     }
 };
+
+// ---- RAW packer primitives (OLD:675-722) ---------------------------------------------------------------------------------
+inline void i2tr(uint32_t v, int w, std::array<UTrit, 27>& d, int s) { for (int i = 0; i < w; ++i) { d[(size_t)(s + i)] = (UTrit)(v % 3); v /= 3; } }
+inline uint32_t tr2i(const std::array<UTrit, 27>& d, int w, int s) { uint32_t val = 0, p = 1; for (int i = 0; i < w; ++i) { val += p * d[(size_t)(s + i)]; p *= 3; } return val; }
+inline void pack_two_pixels(const PixelYCbCrQuant& a, const PixelYCbCrQuant& b, Word27& w) {          // OLD:693-705, one word through K1
+    const PixelYCbCrQuant two[2] = {a, b};
+    if (!t3hip_is_ready()) t3hip_init(0);
+    t3hip_pack_pixels(two, 2, &w);
+}
+inline void unpack_two_pixels(const Word27& w, PixelYCbCrQuant& a, PixelYCbCrQuant& b) {            // OLD:706-722, one word through K5
+    PixelYCbCrQuant two[2];
+    if (!t3hip_is_ready()) t3hip_init(0);
+    if (t3hip_unpack_words(&w, 1, two) == T3_OK) { a = two[0]; b = two[1]; }
+}
+// ---- 2-D boustrophedon on a symbol vector (OLD:750-813) --------------------------------------------------------------------
+inline void interleave2D_boustrophedon(std::vector<GF27>& syms, Tile2D tile) { if (!t3hip_is_ready()) t3hip_init(0); t3hip_interleave2d(syms.data(), syms.size(), tile.w, tile.h, 0); }
+inline void deinterleave2D_boustrophedon(std::vector<GF27>& syms, Tile2D tile) { if (!t3hip_is_ready()) t3hip_init(0); t3hip_interleave2d(syms.data(), syms.size(), tile.w, tile.h, 1); }
 
 // ---- RAW packer (OLD:723-747; `_subword` variants NEWH:113-125 / NEWC:139-155) ------------------------------------
 inline bool encode_raw_pixels_to_words(const std::vector<PixelYCbCrQuant>& px, std::vector<Word27>& out) {
@@ -284,6 +352,31 @@ inline bool decode_frame(const std::vector<Word27>& in, std::vector<PixelYCbCrQu
 
 // ---- self-tests with the reference's inputs (OLD:1172-1230) ------------------------------------------------------------
 // The reference's own versions fail; these run the same inputs through FIXED mode, where they pass.
+inline bool selftest_rs_unit() {   // OLD:1172-1207, same data pattern, error positions and values (std::mt19937 rng(1)); FIXED arithmetic
+    if (!t3::ensure_device()) return false;
+    GF27Context gf; gf.init();
+    std::mt19937 rng(1);
+    for (ProfileID pid : {ProfileID::P1_RS26_24, ProfileID::P2_RS26_22, ProfileID::P3_RS26_20, ProfileID::P4_RS26_18}) {
+        RSCodec rs; rs.mode = T3_MODE_FIXED; rs.init(&gf, rs_params_for(pid));
+        const int n = rs.params.n, k = rs.params.k, t = (n - k) / 2;
+        std::vector<GF27> data((size_t)k);
+        for (int i = 0; i < k; ++i) data[(size_t)i] = (GF27)((i * 5 + 7) % 27);
+        std::vector<GF27> code((size_t)n);
+        if (!rs.encode_block(data.data(), code.data())) return false;
+        std::uniform_int_distribution<int> pos(0, n - 1), val(1, 26);
+        std::vector<int> used;
+        for (int e = 0; e < t; ++e) {
+            int p;
+            do { p = pos(rng); } while (std::find(used.begin(), used.end(), p) != used.end());
+            used.push_back(p);
+            code[(size_t)p] = gf.add(code[(size_t)p], (GF27)val(rng));
+        }
+        std::vector<GF27> outk((size_t)k);
+        if (!rs.decode_block(code.data(), outk.data())) return false;
+        if (outk != data) return false;
+    }
+    return true;
+}
 inline bool selftest_api_roundtrip() {
     std::vector<PixelYCbCrQuant> px(64);
     for (size_t i = 0; i < px.size(); ++i) { px[i].Yq = (uint16_t)(i * 7 % 243); px[i].Cbq = (int16_t)((int)(i * 3 % 81) - 40); px[i].Crq = (int16_t)((int)(i * 5 % 81) - 40); }

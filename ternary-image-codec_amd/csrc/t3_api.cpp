@@ -34,6 +34,10 @@ struct Ctx {
     uint32_t* d_flag = nullptr;                         // failure counter for the synchronous decode entry points
     std::string hip_err;
     std::mutex mu;
+    // The host-buffer entry points share one stream and two scratch slots: each of them holds this for its whole upload ->
+    // launch -> download -> synchronise sequence (two caller threads otherwise interleave on the stream and overwrite, or free,
+    // each other's scratch).  Recursive: some of them are built from others.
+    std::recursive_mutex host_mu;
 };
 Ctx g;
 
@@ -525,6 +529,7 @@ int t3hip_pack_pixels(const void* px, uint64_t n_px, void* words) {
     if (!g.ready) return T3_E_NODEVICE;
     const uint64_t nw = (n_px + 1) / 2; if (!nw) return T3_OK;
     if (!px || !words) return T3_E_ARG;
+    std::lock_guard<std::recursive_mutex> hl(g.host_mu);
     void *di, *dout; int rc;
     { std::lock_guard<std::mutex> lk(g.mu); rc = host_roundtrip_in(0, px, n_px * 6, &di); if (rc) return rc; rc = scratch(1, nw * 9, &dout); if (rc) return rc; }
     rc = t3hip_pack_pixels_dev(di, n_px, dout, g.stream); if (rc) return rc;
@@ -535,6 +540,7 @@ int t3hip_unpack_words(const void* words, uint64_t n_words, void* px) {
     if (!g.ready) return T3_E_NODEVICE;
     if (!n_words) return T3_OK;
     if (!px || !words) return T3_E_ARG;
+    std::lock_guard<std::recursive_mutex> hl(g.host_mu);
     void *di, *dout; int rc;
     { std::lock_guard<std::mutex> lk(g.mu); rc = host_roundtrip_in(0, words, n_words * 9, &di); if (rc) return rc; rc = scratch(1, n_words * 12, &dout); if (rc) return rc; }
     rc = t3hip_unpack_words_dev(di, n_words, dout, g.stream); if (rc) return rc;
@@ -547,6 +553,7 @@ static int encode_host(int fe, const void* in, uint64_t n_units, const t3_cfg* c
     const uint64_t n_raw = fe == FE_PIXELS ? (n_units + 1) / 2 : n_units;
     t3_layout L; int rc = plan(n_raw, *cfg, L); if (rc) return rc;
     *n_out = L.out_words; if (L.out_words > cap) return T3_E_CAPACITY;
+    std::lock_guard<std::recursive_mutex> hl(g.host_mu);
     void *di, *dout;
     { std::lock_guard<std::mutex> lk(g.mu); rc = host_roundtrip_in(0, in, n_units * (fe == FE_PIXELS ? 6 : 9), &di); if (rc) return rc; rc = scratch(1, L.out_words * 9 + 64, &dout); if (rc) return rc; }
     rc = encode_dev(fe, di, n_units, cfg, dout, L.out_words, n_out, g.stream); if (rc) return rc;
@@ -573,4 +580,5 @@ int api_fail_hip(hipError_t e, const char* what) { return fail_hip(e, what); }
 uint32_t* api_flag() { return g.d_flag; }
 RsTables* api_tables() { return g.d_tab; }
 int api_n_cu() { return g.n_cu; }
+std::recursive_mutex& api_host_mutex() { return g.host_mu; }
 }  // namespace t3

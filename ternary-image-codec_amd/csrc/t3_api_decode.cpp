@@ -17,7 +17,7 @@
 
 namespace t3 {
 int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr);
-int api_fail_hip(hipError_t e, const char* what); uint32_t* api_flag(); RsTables* api_tables(); int api_n_cu();
+int api_fail_hip(hipError_t e, const char* what); uint32_t* api_flag(); RsTables* api_tables(); int api_n_cu(); std::recursive_mutex& api_host_mutex();
 }  // namespace t3
 using namespace t3;
 
@@ -457,6 +457,7 @@ int t3hip_decode_profile_dev(const void* d_in, uint64_t n_in, t3_cfg* seen, void
 static int decode_host(const void* in, uint64_t n_in, t3_cfg* seen, void* out, uint64_t cap, uint64_t* n_out, int to_pixels) {
     if (!api_ready()) return T3_E_NODEVICE;
     if (!seen || !n_out || (n_in && !in)) return T3_E_ARG;
+    std::lock_guard<std::recursive_mutex> hl(api_host_mutex());          // one caller at a time on the shared stream and scratch
     void *di, *dout; int rc = api_scratch(0, n_in * 9 + 64, &di); if (rc) return rc;
     const uint64_t unit = to_pixels ? 6 : 9, dcap = (to_pixels ? 2 : 1) * (n_in + 16);
     rc = api_scratch(1, dcap * unit + 64, &dout); if (rc) return rc;
@@ -565,6 +566,7 @@ int t3hip_crc32_dev(const void* d_data, uint64_t n_bytes, uint32_t* crc_out, voi
 int t3hip_crc32(const void* data, uint64_t n_bytes, uint32_t* crc_out) {
     if (!api_ready()) return T3_E_NODEVICE;
     if (!crc_out || (n_bytes && !data)) return T3_E_ARG;
+    std::lock_guard<std::recursive_mutex> hl(api_host_mutex());
     std::lock_guard<std::recursive_mutex> lk(g_mail_mu);
     void* di; int rc = api_scratch(0, n_bytes + 64, &di); if (rc) return rc;
     hipStream_t s = api_stream();

@@ -10,7 +10,7 @@
 #include "t3_rgb.h"
 
 namespace t3 {
-int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr);
+int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr); std::recursive_mutex& api_host_mutex();
 int api_fail_hip(hipError_t e, const char* what);
 }  // namespace t3
 using namespace t3;
@@ -75,6 +75,7 @@ int t3hip_rgb_to_quant(const uint8_t* rgb, uint64_t n_px, void* px6) {
     if (!api_ready()) return T3_E_NODEVICE;
     if (!n_px) return T3_OK;
     if (!rgb || !px6) return T3_E_ARG;
+    std::lock_guard<std::recursive_mutex> hl(api_host_mutex());
     void *di, *dout; int rc = api_scratch(0, 3 * n_px + 64, &di); if (rc) return rc;
     rc = api_scratch(1, 6 * n_px + 64, &dout); if (rc) return rc;
     HIPCHK(hipMemcpyAsync(di, rgb, 3 * n_px, hipMemcpyHostToDevice, api_stream()));
@@ -86,6 +87,7 @@ int t3hip_quant_to_rgb(const void* px6, uint64_t n_px, uint8_t* rgb) {
     if (!api_ready()) return T3_E_NODEVICE;
     if (!n_px) return T3_OK;
     if (!rgb || !px6) return T3_E_ARG;
+    std::lock_guard<std::recursive_mutex> hl(api_host_mutex());
     void *di, *dout; int rc = api_scratch(0, 6 * n_px + 64, &di); if (rc) return rc;
     rc = api_scratch(1, 3 * n_px + 64, &dout); if (rc) return rc;
     HIPCHK(hipMemcpyAsync(di, px6, 6 * n_px, hipMemcpyHostToDevice, api_stream()));

@@ -2,6 +2,7 @@
 // include/ternary_packing.hpp (TPACK:18-65).  Device entry points launch on the caller's stream; host entry points stage
 // through the library's scratch buffers like the rest of the std::vector-facing API.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <string.h>
 
 #include <algorithm>
@@ -10,7 +11,7 @@
 #include "t3_subword.h"
 
 namespace t3 {
-int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr);
+int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr); std::recursive_mutex& api_host_mutex();
 int api_fail_hip(hipError_t e, const char* what);
 }  // namespace t3
 using namespace t3;
@@ -97,6 +98,7 @@ static int fetch(void* out, const void* dout, uint64_t bytes) {
 
 int t3hip_subword_extract(const void* words9, uint64_t n_words, int N, uint8_t* trits) {
     if (!api_ready()) return T3_E_NODEVICE;
+    std::lock_guard<std::recursive_mutex> hl(api_host_mutex());
     if (!valid_n(N)) return T3_E_ARG;
     if (!n_words) return T3_OK;
     if (!words9 || !trits) return T3_E_ARG;
@@ -106,6 +108,7 @@ int t3hip_subword_extract(const void* words9, uint64_t n_words, int N, uint8_t* 
 }
 int t3hip_subword_build(const uint8_t* trits, uint64_t n_trits, int N, uint8_t fill, void* words9, uint64_t cap_words, uint64_t* n_words) {
     if (!api_ready()) return T3_E_NODEVICE;
+    std::lock_guard<std::recursive_mutex> hl(api_host_mutex());
     if (!valid_n(N) || !n_words || (n_trits && !trits)) return T3_E_ARG;
     const uint64_t nw = t3hip_subword_words(n_trits, N); *n_words = nw;
     if (nw > cap_words) return T3_E_CAPACITY;
@@ -117,6 +120,7 @@ int t3hip_subword_build(const uint8_t* trits, uint64_t n_trits, int N, uint8_t f
 }
 int t3hip_base243_pack(const uint8_t* trits, uint64_t n_trits, uint8_t* out, uint64_t cap_bytes, uint64_t* n_bytes) {
     if (!api_ready()) return T3_E_NODEVICE;
+    std::lock_guard<std::recursive_mutex> hl(api_host_mutex());
     if (!n_bytes || n_trits > 0xFFFFFFFFull || (n_trits && !trits)) return T3_E_ARG;
     *n_bytes = t3hip_base243_bytes(n_trits);
     if (*n_bytes > cap_bytes) return T3_E_CAPACITY;
@@ -127,6 +131,7 @@ int t3hip_base243_pack(const uint8_t* trits, uint64_t n_trits, uint8_t* out, uin
 }
 int t3hip_base243_unpack(const uint8_t* in, uint64_t n_bytes, uint8_t* trits, uint64_t cap_trits, uint64_t* n_trits) {
     if (!api_ready()) return T3_E_NODEVICE;
+    std::lock_guard<std::recursive_mutex> hl(api_host_mutex());
     if (!n_trits || (n_bytes && !in)) return T3_E_ARG;
     *n_trits = 0;
     if (n_bytes < 4) return T3_E_HEADER;
@@ -142,6 +147,7 @@ int t3hip_base243_unpack(const uint8_t* in, uint64_t n_bytes, uint8_t* trits, ui
 }
 int t3hip_mod27_bytes(const uint8_t* in, uint64_t n, uint8_t* out) {
     if (!api_ready()) return T3_E_NODEVICE;
+    std::lock_guard<std::recursive_mutex> hl(api_host_mutex());
     if (!n) return T3_OK;
     if (!in || !out) return T3_E_ARG;
     void *di, *dout; int rc = roundtrip(in, n, &di, n, &dout); if (rc) return rc;

@@ -182,6 +182,9 @@ __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_px_kern
     } else {
         // ---------------- consumers: BM + D5 of the tile the producers finished in the previous interval ----------------
         const uint32_t cw = wave - 4u;
+#ifdef T3_DEC_CONS_PRIO
+        __builtin_amdgcn_s_setprio(T3_DEC_CONS_PRIO);                               // the correction is one long dependent chain: let its steps issue first
+#endif
         for (uint32_t k = 0; k <= n_my; ++k) {
             if (k >= 1u) {
                 const uint32_t tile = blockIdx.x + (k - 1u) * grid, buf = (k - 1u) & 1u;

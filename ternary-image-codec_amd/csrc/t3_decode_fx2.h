@@ -96,31 +96,41 @@ __device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], c
     // which K..25 are parity; lanes without a block write into a dummy area instead of being masked off store by store
     const uint32_t ya = b.valid ? b.yb + 117u * h : kFx2Dummy;                     // 9 * 13
     v16i_ acc = {81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81};     // bias: trit sums in [-78, 78] -> [3, 159]
-#pragma unroll
-    for (uint32_t st = 0; st < 4; ++st) {
-        v4i_ Bv = {0, 0, 0, 0};
-        uint32_t xs[4] = {0, 0, 0, 0};
+    // The table reads of K-step st + 1 are issued before the MFMA of step st (one step of entries in flight beside the one being
+    // consumed: the LDS latency of a step hides under the previous step's MFMA), no further (80-VGPR budget).
+    auto fetch = [&](const uint32_t st, v4i_& Bv) {
+        Bv = v4i_{0, 0, 0, 0};
 #pragma unroll
         for (uint32_t d = 0; d < 4; ++d) {
             const uint32_t q = 4u * st + d;
             if (q >= 13u) continue;
             const uint32_t c = (W[st] >> (8u * d)) & 0xFFu;
             const uint32_t base = q == 0 ? vb0 : q == 1 ? vb1 : vb[q % 6u];
-            const uint32_t x = *T3_LP(const uint32_t, c * (4u * TCOP) + base);
-            Bv[d] = (int)x; xs[d] = x;
-            if (q + 13u < K) *T3_LP(uint8_t, ya + 9u * q) = (uint8_t)(x >> 16);   // both halves hold data here
+            Bv[d] = (int)*T3_LP(const uint32_t, c * (4u * TCOP) + base);
         }
+    };
+    auto emit = [&](const uint32_t st, const v4i_& Bv) {       // data symbols of the step -> stream order
+#pragma unroll
+        for (uint32_t d = 0; d < 4; ++d) { const uint32_t q = 4u * st + d; if (q < 13u && q + 13u < K) *T3_LP(uint8_t, ya + 9u * q) = (uint8_t)((uint32_t)Bv[d] >> 16); }   // both halves hold data here
         if (4u * st + 3u + 13u >= K) {                                              // positions >= K - 13 of the upper half are parity: one masked region per step
             if (h == 0) {
 #pragma unroll
-                for (uint32_t d = 0; d < 4; ++d) { const uint32_t q = 4u * st + d; if (q < 13u && q + 13u >= K) *T3_LP(uint8_t, ya + 9u * q) = (uint8_t)(xs[d] >> 16); }
+                for (uint32_t d = 0; d < 4; ++d) { const uint32_t q = 4u * st + d; if (q < 13u && q + 13u >= K) *T3_LP(uint8_t, ya + 9u * q) = (uint8_t)((uint32_t)Bv[d] >> 16); }
             }
         }
+    };
+    v4i_ Bcur, Bnext;
+    fetch(0, Bcur);
+#pragma unroll
+    for (uint32_t st = 0; st < 4; ++st) {
+        if (st < 3u) fetch(st + 1u, Bnext);
         // the syndrome matrix lives in LDS (80-VGPR budget): three full steps, then step 3 of which only dword 0 (position 12) is used
         v4i_ Af = {0, 0, 0, 0};
         if (st < 3u) Af = *T3_LP(const v4i_, af_off + 16u * (64u * st + lane)); else Af[0] = *T3_LP(const int, af_off + 3072u + 4u * lane);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af, Bv, acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);                                          // one K-step's table entries live at a time (80-VGPR budget)
+        emit(st, Bcur);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af, Bcur, acc, 0, 0, 0);
+        Bcur = Bnext;
+        __builtin_amdgcn_sched_barrier(0);
     }
     uint32_t Pown = 0;
 #pragma unroll

@@ -14,6 +14,7 @@ template <int FE, bool IL, int RSEL> __global__ void encode_kernel_k(const EncAr
 template <int FE, bool IL> __global__ void encode_kernel_mixed(const EncArgs a);         // mixed k (UEP), LUT path
 template <int FE, bool IL> __global__ void encode_kernel_uep(const EncArgs a);           // mixed k (UEP), matrix cores: bands grouped by k
 __global__ void beacon_kernel(const BeaconArgs a);
+__global__ void interleave_kernel(const uint8_t* in, uint8_t* out, uint32_t n, uint32_t w, uint32_t A, DevDiv div_A, DevDiv div_w);   // OLD:750-813, standalone
 __global__ void rs_encode_blocks_kernel(const uint8_t* data, uint64_t n_blocks, int k, const uint8_t* P, const RsTables* tab, uint8_t* code);
 
 }  // namespace t3

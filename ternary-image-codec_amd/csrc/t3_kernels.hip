@@ -1085,6 +1085,19 @@ __global__ __launch_bounds__(256) void beacon_kernel(const BeaconArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// standalone 2-D boustrophedon (interleave2D_boustrophedon / deinterleave2D_boustrophedon OLD:750-813): out[u] = in[perm(u)].
+// The map is an involution inside every row segment (odd rows of a chunk reversed, the stream's ragged last rows within
+// their own length), so one kernel serves both directions.  API completeness: the frame kernels carry the map fused.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void interleave_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n, uint32_t w, uint32_t A, DevDiv div_A, DevDiv div_w) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    const uint32_t chunk = fdiv(u, div_A), base = chunk * A, rem = u - base, take = min(A, n - base);
+    const uint32_t r = fdiv(rem, div_w), c = rem - r * w, rowlen = min(w, take - r * w);
+    out[u] = in[base + r * w + ((r & 1u) ? rowlen - 1u - c : c)];
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // block-level RS encode (RSCodec::encode_block OLD:517-535): out = data || data * P
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rs_encode_blocks_kernel(const uint8_t* __restrict__ data, uint64_t n_blocks, int k,

@@ -140,7 +140,7 @@ def main():
     if args.with_8k:
         px = orc.lcg_pixels(7680 * 4320)
         ent = {"cfgs": {}}
-        for name in ("p3_uniform20", "p5_tile64_luma"):
+        for name in ("p3_uniform20", "p5_tile64_luma", "p2_beacon83"):
             cfg = ol.make_cfg(**FRAME_CFGS[name])
             rc, enc = ref.encode_frame(px, cfg, cap=len(px))
             assert rc == 0

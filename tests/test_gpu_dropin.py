@@ -20,6 +20,85 @@ def build_demo(tmp):
     return exe
 
 
+def build_refnames(tmp, src=None):
+    exe = os.path.join(tmp, "refnames_demo" if src is None else "ref_main_bare")
+    lib = os.path.join(ROOT, "ternary-image-codec_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include", "compat"), "-I" + os.path.join(ROOT, "include"),
+                    src or os.path.join(ROOT, "tests", "cpp", "refnames_demo.cpp"), "-L" + lib, "-lt3hip", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    return exe
+
+
+def test_reference_caller_compiles_against_dropin_header(t3, tmp_path):
+    """The reference's own self-test runner (old/src/main_bare.cpp: includes "ternary_image_codec_v6_min.hpp", calls selftest_rs_unit
+    and selftest_api_roundtrip) compiles UNCHANGED against include/compat + include/ternary_codec_v6.hpp with g++ alone, and so
+    does tests/cpp/refnames_demo.cpp, which touches every other public name of the path.  Without a GPU both answer false /
+    T3_E_NODEVICE (no fallback).  The reference source is read where it lies, only in this container."""
+    import torch
+    exe2 = build_refnames(str(tmp_path))
+    ref_main = "/root/reference/old/src/main_bare.cpp"
+    exe = build_refnames(str(tmp_path), ref_main) if os.path.exists(ref_main) else None
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu test")
+    if exe:
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 1 and r.stdout.strip() == "RS:FAIL API:FAIL"          # no device: every call returns false
+    out = json.loads(subprocess.run([exe2], check=True, capture_output=True, text=True).stdout)
+    assert out["selftest_rs_unit"] == 0 and out["selftest_api_roundtrip"] == 0
+    # the host-side control arithmetic needs no device: field, generator polynomials, scrambler, beacon symbol, CRC-12
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_vectors.json")))
+    assert out["primitive"] == 3 and out["order3"] == 26 and out["scr_back"] == 1 and out["tr2i"] == 200
+
+
+@pytest.mark.gpu
+def test_reference_names_on_device(gpu, orc, tmp_path):
+    """tests/cpp/refnames_demo.cpp on the card, every value against the oracle / the golden vectors captured from the reference."""
+    out = json.loads(subprocess.run([build_refnames(str(tmp_path))], check=True, capture_output=True, text=True).stdout)
+    assert out["selftest_rs_unit"] == 1 and out["selftest_api_roundtrip"] == 1 and out["status"] == 0
+    gfm = orc.gf_tables()
+    fld = []
+    for a in range(27):
+        for b in range(27):
+            ta = [(a // 3 ** i) % 3 for i in range(3)]; tb = [(b // 3 ** i) % 3 for i in range(3)]
+            s_ = sum(((ta[i] + tb[i]) % 3) * 3 ** i for i in range(3)); d_ = sum(((ta[i] - tb[i]) % 3) * 3 ** i for i in range(3))
+            m = int(gfm["mul"][a * 27 + b])
+            fld += [s_, d_, m, m]
+    for a in range(27):
+        fld += [int(gfm["inv"][a]), int(gfm["log"][a]) & 0xFF]
+    for e in range(-30, 60):
+        fld.append(int(gfm["exp"][e % 26]))
+    assert out["field_hash"] == ol.fnv_hex(np.array(fld, np.uint8)) and out["primitive"] == gfm["prim"] == 3 and out["order3"] == 26
+    # RSCodec in COMPAT arithmetic = the reference's encode_block / decode_block (oracle pinned to it)
+    rsv = []; dec_ok = 0
+    for k in (24, 22, 20, 18):
+        g = orc.rs_generator(k)
+        data = np.array([(i * 5 + 7) % 27 for i in range(k)], np.uint8)
+        code = orc.rs_encode_blocks(k, data, 0)[0]
+        rsv += list(g) + list(code)
+        for x in range(27):          # Horner, as poly_eval
+            acc = 0
+            for c in reversed(list(g)):
+                acc = int(gfm["mul"][acc * 27 + x]); ta = [(acc // 3 ** i) % 3 for i in range(3)]; tc = [(int(c) // 3 ** i) % 3 for i in range(3)]
+                acc = sum(((ta[i] + tc[i]) % 3) * 3 ** i for i in range(3))
+            rsv.append(acc)
+        bad = code.copy(); t3_ = [(int(bad[3]) // 3 ** i) % 3 for i in range(3)]; f5 = [2, 1, 0]
+        bad[3] = sum(((t3_[i] + f5[i]) % 3) * 3 ** i for i in range(3))
+        cw, dk, okv = orc.rs_decode_blocks(k, bad, 0)
+        dec_ok = dec_ok * 2 + int(okv[0])
+        rsv += list(cw[0]) + (list(dk[0]) if okv[0] else [77] * k)
+    assert out["rs_hash"] == ol.fnv_hex(np.array(rsv, np.uint8)) and out["dec_ok"] == dec_ok
+    scr = []
+    for seed in ((1, 1, 1), (0xFFFFFFFF, 0xFFFFFFFE, 5)):
+        scr += list(orc.scramble(np.array([i % 27 for i in range(60)], np.uint8), *seed, 0))
+    assert out["scr_hash"] == ol.fnv_hex(np.array(scr, np.uint8)) and out["scr_back"] == 1
+    bea = [orc.beacon_symbol(p, f, h) for p in range(5) for f in (0, 1, 2, 4, 8192 % 5) for h in range(3)]
+    assert out["beacon_hash"] == ol.fnv_hex(np.array(bea, np.uint8))
+    msg = np.array([(i * 7 + i // 5) % 3 for i in range(69)], np.uint8)
+    assert out["crc12"] == "".join(str(int(x)) for x in orc.crc12(msg))
+    il = np.array([(i * 11 + i // 7) % 27 for i in range(1000)], np.uint8)
+    assert out["il_hash"] == ol.fnv_hex(orc.interleave2d(il, 7, 5, 0)) and out["il_back"] == 1
+    assert out["word"] == [21, 5, 13, 7, 26, 1, 17, 20, 6] and out["unpack_equal"] == 1 and out["tr2i"] == 200     # SURVEY appendix A
+
+
 def test_dropin_header_compiles_and_refuses_without_gpu(t3, tmp_path):
     """CPU: the header builds with g++ alone; with no device every call returns false with T3_E_NODEVICE (no fallback)."""
     import torch

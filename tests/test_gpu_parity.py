@@ -159,14 +159,16 @@ def test_golden_frame_hashes(gpu, orc, res):
     assert list(enc.reshape(-1)) == st["p2_luma_words"]
 
 
-@pytest.mark.parametrize("name", ["p3_uniform20", "p5_tile64_luma"])
+@pytest.mark.parametrize("name", ["p3_uniform20", "p5_tile64_luma", "p2_beacon83"])
 def test_8k_frame_hash(gpu, orc, name):
-    """BASELINE configs 2 and 3 at full size: device-resident fused encode, hash captured from the reference."""
+    """BASELINE configs 2 and 3 (and a beacon configuration) at full size: device-resident fused encode, hash captured from
+    the reference."""
     import torch
     ent = GOLD["frames"]["7680x4320"]["cfgs"][name]
     px = orc.lcg_pixels(7680 * 4320)
     c = ol.cfg_from_dict(ent["cfg"])
-    cfg = gpu.make_cfg(profile=c.profile, uep=list(c.band_profile), tile=(c.tile_w, c.tile_h))
+    cfg = gpu.make_cfg(profile=c.profile, uep=list(c.band_profile), tile=(c.tile_w, c.tile_h),
+                       beacon=(c.beacon_words_period, c.beacon_band_slot, c.beacon_enabled))
     d_px = torch.from_numpy(px.view(np.uint8)).cuda()
     cap = gpu.encoded_words(len(px) // 2, cfg)
     assert cap == ent["out_words"]
@@ -176,6 +178,61 @@ def test_8k_frame_hash(gpu, orc, name):
     enc = d_out.cpu().numpy()
     assert n == ent["out_words"] and ol.fnv_hex(enc) == ent["hash"]
     assert orc.crc32(enc) == ent["crc32"]
+
+
+@pytest.mark.parametrize("name,kw,max_err", [
+    ("C2 RS(26,20) 1-D (fused decoder)", dict(profile=2, uep=2), 3),                                # BASELINE configs[4]
+    ("C2 clean", dict(profile=2, uep=2), 0),
+    ("C3 2-D 64x64 + luma UEP (two-kernel decoder)", dict(profile=4, uep="luma", tile=(64, 64)), 2),  # BASELINE configs[2]
+    ("C3 clean", dict(profile=4, uep="luma", tile=(64, 64)), 0),
+    ("RS(26,18) 1-D, t = 4", dict(profile=3, uep=3), 4),
+])
+def test_8k_fixed_decode_recovers_frame(gpu, orc, name, kw, max_err):
+    """BASELINE configs[4] at full size: an 8K FIXED (v6c) stream with 0..t injected symbol errors in EVERY RS block decodes back
+    to the exact pixels and to the exact 26-trit words, through both device entry points (synchronous with host-parsed header,
+    streaming with the known configuration), verdict words clean.  Size-independent property (encode -> corrupt -> decode =
+    identity); the small-size tests pin the same path against the oracle byte for byte."""
+    import torch
+    NPX = 7680 * 4320
+    px = orc.lcg_pixels(NPX, 4711)
+    d_px = torch.from_numpy(px.view(np.uint8)).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    cfg, _ = both(gpu, kw, mode=1)
+    n_raw = NPX // 2; n_enc = gpu.encoded_words(n_raw, cfg)
+    coded = torch.zeros(n_enc * 9 + 64, dtype=torch.uint8, device="cuda")
+    assert gpu.encode_frame_dev(d_px.data_ptr(), NPX, cfg, coded.data_ptr(), n_enc, s) == n_enc
+    L = gpu.plan(n_raw, cfg)
+    if max_err:
+        clean = coded.clone()
+        gpu.inject_errors_dev(coded.data_ptr(), L.header_syms, L.body_syms // 26, 20261004, max_err, s)
+        torch.cuda.synchronize()
+        n_bad = int((coded != clean).sum().item())
+        assert n_bad > (L.body_syms // 26) // 2                       # most blocks really carry errors
+        del clean
+    out = torch.zeros(NPX * 6 + 64, dtype=torch.uint8, device="cuda")
+    seen = gpu.DecoderContext(mode=1).cfg_last_seen
+    rc, n = gpu.decode_profile_dev(coded.data_ptr(), n_enc, seen, out.data_ptr(), NPX, True, s)
+    assert rc == 0 and n == NPX and bool(torch.equal(out[: NPX * 6], d_px)), name
+    out.zero_(); ver = torch.full((2,), 7, dtype=torch.int32, device="cuda")
+    assert gpu.decode_frame_async(coded.data_ptr(), n_enc, seen, n_raw, out.data_ptr(), NPX, ver.data_ptr(), True, s) == NPX
+    torch.cuda.synchronize()
+    assert ver.cpu().tolist() == [0, 0] and bool(torch.equal(out[: NPX * 6], d_px)), name
+    raw = torch.zeros(n_raw * 9 + 64, dtype=torch.uint8, device="cuda")
+    gpu.pack_pixels_dev(d_px.data_ptr(), NPX, raw.data_ptr(), s)
+    out.zero_()
+    rc, n = gpu.decode_profile_dev(coded.data_ptr(), n_enc, seen, out.data_ptr(), n_raw, False, s)
+    assert rc == 0 and n == n_raw and bool(torch.equal(out[: n_raw * 9], raw[: n_raw * 9])), name
+    if max_err:   # one block beyond its code's reach -> detected (reference-style false), nothing else disturbed
+        flat = coded[: n_enc * 9]
+        flat[L.header_syms: L.header_syms + 13] = (flat[L.header_syms: L.header_syms + 13] + 1) % 27
+        ver.fill_(7)
+        gpu.decode_frame_async(coded.data_ptr(), n_enc, seen, n_raw, out.data_ptr(), NPX, ver.data_ptr(), True, s)
+        torch.cuda.synchronize()
+        v = ver.cpu().tolist()
+        host = flat[L.header_syms: L.header_syms + 26].cpu().numpy()
+        k0 = int(L.band_k[0])
+        _, _, okb = orc.rs_decode_blocks(k0, ol.oracle().scramble(host, seen.seed_a, seen.seed_b, seen.seed_s0, 1), mode=1)
+        assert v[0] == 0 and (v[1] == 0) == bool(okb[0]), (name, v, okb)
 
 
 def test_decode_compat_golden_streams(gpu, orc):
@@ -553,6 +610,35 @@ def test_rgb_frame_encode_decode(t3, orc, gpu, npx):
     torch.cuda.synchronize()
     assert ver.cpu().numpy().tolist() == [0, 0]
     assert np.array_equal(d_back[: 3 * npx].cpu().numpy(), np.asarray(orc.quant_to_rgb(q)).reshape(-1))
+
+
+@pytest.mark.gpu
+def test_host_api_two_threads(gpu, orc):
+    """The std::vector-shaped entry points share one stream and two scratch slots inside the library; two caller threads encoding
+    and decoding DIFFERENT frames of different sizes at the same time must each get their own frame's bytes (the library holds
+    a host-path mutex over upload -> launch -> download; ctypes drops the GIL, so the calls really overlap)."""
+    import threading
+    res = {}
+    def work(tag, n, seed, kw):
+        try:
+            cfg, ocfg = both(gpu, kw, mode=1)
+            for rep in range(6):
+                px = orc.lcg_pixels(n + 17 * rep, seed + rep)
+                ok, enc = gpu.encode_frame(px, cfg)
+                rc, want = orc.encode_frame(px, ocfg, cap=len(px) + 64)
+                assert ok and rc == 0 and np.array_equal(enc, want), (tag, rep, "encode")
+                okd, back = gpu.decode_frame(enc, gpu.DecoderContext(mode=1))
+                assert okd and np.array_equal(back[: len(px)], px), (tag, rep, "decode")
+                raw = gpu.encode_raw_pixels_to_words(px)
+                assert np.array_equal(raw, orc.pack_pixels(px)), (tag, rep, "pack")
+            res[tag] = "ok"
+        except Exception as e:   # noqa: BLE001
+            res[tag] = repr(e)
+    th = [threading.Thread(target=work, args=("a", 200_003, 11, dict(profile=2, uep=2))),
+          threading.Thread(target=work, args=("b", 90_001, 77, dict(profile=4, uep="luma", tile=(64, 64))))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert res == {"a": "ok", "b": "ok"}, res
 
 
 @pytest.mark.gpu
