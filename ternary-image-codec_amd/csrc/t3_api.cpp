@@ -1,6 +1,7 @@
 // t3_api.cpp — the C-ABI of libt3hip.so (include/t3hip.h): context, tile planning, kernel launches.
 // Host logic only; all arithmetic on the data path happens in t3_kernels.hip / t3_decode.hip.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -150,12 +151,12 @@ uint32_t p1_waves_per_parity(uint32_t TS) {
 // dealt linearly into sets of 32; eight waves take two sets each
 bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, int fe, const LutImage& lut, EncLaunch& out, bool grp = false) {
     EncArgs& a = out.a; memset(&a, 0, sizeof a);
-    const uint32_t GS = fe == FE_PIXELS ? kGroupSyms : kGroupSymsW, GB = fe == FE_PIXELS ? kGroupBytes : kGroupBytesW;
+    const uint32_t GS = fe_px(fe) ? kGroupSyms : kGroupSymsW, GB = fe == FE_PIXELS ? kGroupBytes : fe == FE_RGB ? kGroupBytesRgb : kGroupBytesW;
     uint64_t Lk = 2;
     for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) Lk = Lk / gcd64(Lk, L.band_k[b]) * L.band_k[b];
     uint32_t lut_bytes = lut.bytes;
     // 2-D through the pipelined flow: a tile's input then covers the row segments it overlaps (up to w - 1 extra symbols each side)
-    const bool il_async = L.interleave2d && fe == FE_PIXELS && cfg.tile_w <= 512;
+    const bool il_async = L.interleave2d && fe_px(fe) && cfg.tile_w <= 512;
     const uint32_t il_extra = il_async ? 2u * cfg.tile_w : 0u;
     const uint32_t hdr = grp ? (uint32_t)kLdsHdrUep : (uint32_t)kLdsHdr;
     bool mixed = false;
@@ -184,15 +185,15 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
             }
             if (waves > (pass == 0 ? 8u : (uint32_t)kMaxWaves)) break;   // pass 0: 512-thread workgroups, three per CU
             const uint32_t groups = (uint32_t)((9 * Lq + il_extra) / GS) + 8, stage = groups * GB + 1024 + 32;   // +1 KiB: LDS-DMA pieces are whole
-            const uint32_t total = hdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq) + il_extra) + kSymBack + ((L.interleave2d && !il_async) ? 1u : 2u) * round16(stage);
+            const uint32_t total = hdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq) + il_extra) + kSymBack + ((L.interleave2d && !il_async) ? 1u : 2u) * round16(stage) + (fe == FE_RGB ? 256u : 0u);
             if (total > budget) break;
             // wave-instructions per stream symbol: phase 2 costs ~180 per wave, phase 1 (pixels) ~120 per wave-iteration
             const uint32_t wpp = p1_waves_per_parity((uint32_t)(9 * Lq) + il_extra);
-            if (fe == FE_PIXELS && wpp > std::max(waves, 4u)) continue;
+            if (fe_px(fe) && wpp > std::max(waves, 4u)) continue;
             // UEP kernel: the phases are barrier-separated and a wave runs its sets one after the other, so a tile costs one
             // phase-1 pass plus ceil(sets / 8) set times, whatever the number of busy waves
             const double cost = grp ? (220.0 + 100.0 * ((sets + 7) / 8)) / (double)(9 * Lq)
-                                    : (180.0 * waves + (fe == FE_PIXELS ? 220.0 * wpp : 180.0 * waves)) / (double)(9 * Lq);
+                                    : (180.0 * waves + (fe_px(fe) ? 220.0 * wpp : 180.0 * waves)) / (double)(9 * Lq);
             const double score = 1.0 / cost + 1e-9 * (double)Lq;
             if (score > best_score) { best_score = score; best_q = q; }
         }
@@ -219,6 +220,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     { uint32_t acc = 0; for (int b = 0; b < 9; ++b) { a.band_first[b] = acc; acc += a.band_nb_tile[b]; } a.band_first[9] = acc; }
     a.stage_stride = round16(a.stage_groups * GB + 1024 + 32);
     a.lds_bytes = a.stage_off + ((L.interleave2d && !il_async) ? 1u : 2u) * a.stage_stride;   // pipelined flow: two stage buffers (the next tile streams in early)
+    if (fe == FE_RGB) { a.qt_off = a.lds_bytes; a.lds_bytes += 256u; }                            // chroma quantiser table of the fused bridge
     a.il_async = il_async ? 1u : 0u;
     a.n_sym = (uint32_t)L.n_sym;
     const ScrCycle sc = scrambler_cycle(cfg.seed_a, cfg.seed_b, cfg.seed_s0);
@@ -326,16 +328,32 @@ template <int FE, bool IL> int launch_enc2(const EncLaunch& e, hipStream_t s) {
     return launch_fn(fn, e, s);
 }
 template <int FE> int launch_enc(const EncLaunch& e, hipStream_t s) { return e.a.il_on ? launch_enc2<FE, true>(e, s) : launch_enc2<FE, false>(e, s); }
+int launch_enc_fe(int fe, const EncLaunch& e, hipStream_t s) { return fe == FE_PIXELS ? launch_enc<FE_PIXELS>(e, s) : fe == FE_RGB ? launch_enc<FE_RGB>(e, s) : launch_enc<FE_WORDS>(e, s); }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+// chroma quantiser of the fused RGB front end: C -> clamp(lround((C - 128) * (40.0 / 128.0)), -40, 40) + 40 (io_image.hpp:73-76), the
+// reference's own double expression tabulated on the host
+int rgb_quant_table(const uint8_t** out) {
+    static uint8_t* d_qt = nullptr;
+    if (!d_qt) {
+        uint8_t t[256];
+        for (int c = 0; c < 256; ++c) { long v = lround((c - 128) * (40.0 / 128.0)); v = v < -40 ? -40 : (v > 40 ? 40 : v); t[c] = (uint8_t)(v + 40); }
+        HIPCHK(hipMalloc((void**)&d_qt, sizeof t)); HIPCHK(hipMemcpy(d_qt, t, sizeof t, hipMemcpyHostToDevice));
+    }
+    *out = d_qt; return T3_OK;
+}
 
 // pixels|raw words (device) -> coded stream (device)
 int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, void* d_out, uint64_t cap_words, uint64_t* n_out, hipStream_t s) {
     if (!g.ready) return T3_E_NODEVICE;
+    if (fe == FE_RGB && cfg && n_out && d_in && !aligned16(d_in)) return 1;      // the bridge kernel takes any alignment
     if (!cfg || !n_out || (n_units && !d_in) || !aligned16(d_in) || !aligned16(d_out)) return T3_E_ARG;
-    const uint64_t n_raw = fe == FE_PIXELS ? (n_units + 1) / 2 : n_units;
+    const uint64_t n_raw = fe_px(fe) ? (n_units + 1) / 2 : n_units;
     t3_layout L; int rc = plan(n_raw, *cfg, L); if (rc != T3_OK) return rc;
     *n_out = L.out_words;
+    // the fused RGB front end rides the pipelined flow only: RAW mode and 2-D rows wider than 512 go through the bridge kernel (1 = not taken)
+    if (fe == FE_RGB && (cfg->profile == T3_RAW_MODE || (L.interleave2d && cfg->tile_w > 512))) return 1;
     if (L.out_words > cap_words) return T3_E_CAPACITY;
     if (L.out_words && !d_out) return T3_E_ARG;
     if (cfg->profile == T3_RAW_MODE) {                                   // OLD:1046-1050: out = in
@@ -378,10 +396,11 @@ int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, vo
             if (!plan_enc_group(L, *cfg, m, fe, *lut, e)) return T3_E_ARG;
         }
         e.a.afrag = mfma ? lut->d_afrag : nullptr;
-        e.a.in = (const uint8_t*)d_in; e.a.n_units = n_units; e.a.n_units_pad = fe == FE_PIXELS ? 2 * n_raw : n_units;
+        e.a.in = (const uint8_t*)d_in; e.a.n_units = n_units; e.a.n_units_pad = fe_px(fe) ? 2 * n_raw : n_units;
+        if (fe == FE_RGB) { rc = rgb_quant_table(&e.a.qt); if (rc) return rc; }
         e.a.body_out = body_out; e.a.frame_out = first ? frame_out : nullptr; e.a.lut_img = lut->d_img;
         e.a.hdr_syms = hs; e.a.pad_bytes = pad; e.a.out_syms = L.out_syms; memcpy(e.a.hdr, hdr, sizeof hdr);
-        rc = fe == FE_PIXELS ? launch_enc<FE_PIXELS>(e, s) : launch_enc<FE_WORDS>(e, s);
+        rc = launch_enc_fe(fe, e, s);
         if (rc) return rc;
         first = false;
     }
@@ -573,6 +592,7 @@ int t3hip_event_destroy(void* ev) { HIPCHK(hipEventDestroy((hipEvent_t)ev)); ret
 
 // decode-side entry points live in t3_api_decode.cpp (same library)
 namespace t3 {
+int api_encode_rgb_fused(const void* d_rgb, uint64_t n_px, const t3_cfg* cfg, void* d_out, uint64_t cap, uint64_t* n_out, hipStream_t s) { return encode_dev(FE_RGB, d_rgb, n_px, cfg, d_out, cap, n_out, s); }
 int api_ready() { return g.ready ? 1 : 0; }
 hipStream_t api_stream() { return g.stream; }
 int api_scratch(int slot, size_t bytes, void** out, hipStream_t s) { std::lock_guard<std::mutex> lk(g.mu); return scratch(slot, bytes, out, s); }

@@ -1,6 +1,7 @@
 // t3_api_decode.cpp — decode-side half of the C-ABI (include/t3hip.h): header parse on the host, body kernels
 // on the device, block-level decode, error injector, frame index record.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -92,6 +93,19 @@ int ensure_fx_tables(int k) {
     return T3_OK;
 }
 
+// dequantiser tables of the fused RGB output stage (old/include/io_image.hpp:79-84: the reference's double expressions, tabulated)
+int rgb_dequant_tables(const uint8_t** out) {
+    static uint8_t* d = nullptr;
+    if (!d) {
+        uint8_t t[328]; memset(t, 0, sizeof t);
+        auto cl = [](long v) { return v < 0 ? 0 : (v > 255 ? 255 : v); };
+        for (int q = 0; q <= 242; ++q) t[q] = (uint8_t)cl(lround(q * (255.0 / 242.0)));
+        for (int q = -40; q <= 40; ++q) t[244 + q + 40] = (uint8_t)cl(lround(128 + q * (128.0 / 40.0)));
+        HIPCHK(hipMalloc((void**)&d, sizeof t)); HIPCHK(hipMemcpy(d, t, sizeof t, hipMemcpyHostToDevice));
+    }
+    *out = d; return T3_OK;
+}
+
 // `body`: the coded stream with `hdr_syms` symbols of header in front of the band-serial body (the caller has stripped a beacon)
 int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_syms, const t3_layout& L, const ScrCycle& sc,
                        void* d_out, uint64_t units, int to_pixels, uint32_t* d_fail, hipStream_t s) {
@@ -103,6 +117,8 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
     DecFx2Args a; memset(&a, 0, sizeof a);
     a.in = body; a.in_bytes = body_bytes; a.out = d_out; a.n_units = units; a.fail = d_fail; a.roots = d_roots[ki];
     a.ttab = to_pixels ? d_synd_T16 : d_synd_T; a.small = d_fx2_small; a.afrag = d_synd_afrag[ki];
+    const bool rgb = to_pixels == 2;
+    if (rgb) { const int rc = rgb_dequant_tables(&a.dq); if (rc) return rc; }
     a.k = (uint32_t)k; a.nb = 52; a.div_nb = to_dev(fastdiv(a.nb)); a.TS = 9u * 52u * (uint32_t)k; a.n_sym = (uint32_t)L.n_sym; a.hdr_syms = hdr_syms;
     uint64_t maxb = 0;
     for (int b = 0; b < 9; ++b) { a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b]; a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6); maxb = std::max<uint64_t>(maxb, L.band_blocks[b]); }
@@ -115,8 +131,8 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
         a.af_off = a.fma_off + 19696u;
         a.y_off = a.af_off + 3328u; a.y_stride = ybytes;
         a.q_off = a.y_off + 2u * ybytes; a.q_stride = 10u * (uint32_t)kFx2QCap;    // 8 bytes of syndromes + 2 of item number per entry
-        a.o_off = a.q_off + 2u * a.q_stride;
-        a.lds_bytes = a.o_off + 16u;                                                // <= 42 x 1280 B: LDS is handed out in 1280-byte units, 128 per CU (three workgroups)
+        a.o_off = a.q_off + 2u * a.q_stride; a.dq_off = a.o_off;
+        a.lds_bytes = a.o_off + (rgb ? 336u : 16u);                                 // <= 42 x 1280 B: LDS is handed out in 1280-byte units, 128 per CU (three workgroups)
     } else {           // [hdr][fold 3072][T32 3584][FMA][A operand][Y][Q][words]
         a.fma_off = (uint32_t)kFx2TSeq + 3u * 27u * 4u * 32u;
         a.af_off = a.fma_off + 19696u;
@@ -127,10 +143,12 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
     }
     const void* fn = nullptr;
     switch (26 - k) {
-        case 2: fn = to_pixels ? (const void*)decode_fixed_px_kernel<2> : (const void*)decode_fixed_kernel<2>; break;
-        case 4: fn = to_pixels ? (const void*)decode_fixed_px_kernel<4> : (const void*)decode_fixed_kernel<4>; break;
-        case 6: fn = to_pixels ? (const void*)decode_fixed_px_kernel<6> : (const void*)decode_fixed_kernel<6>; break;
-        default: fn = to_pixels ? (const void*)decode_fixed_px_kernel<8> : (const void*)decode_fixed_kernel<8>; break;
+#define T3_PICK(R) (rgb ? (const void*)decode_fixed_px_kernel<R, true> : to_pixels ? (const void*)decode_fixed_px_kernel<R, false> : (const void*)decode_fixed_kernel<R>)
+        case 2: fn = T3_PICK(2); break;
+        case 4: fn = T3_PICK(4); break;
+        case 6: fn = T3_PICK(6); break;
+        default: fn = T3_PICK(8); break;
+#undef T3_PICK
     }
     static std::map<const void*, int> occ;
     auto it = occ.find(fn);
@@ -262,6 +280,10 @@ int decode_fixed_stream(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_s
 int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_raw, const uint8_t next[3],
                 void* d_out, uint64_t cap_units, uint64_t* n_out, int to_pixels, uint32_t* d_fail, hipStream_t s) {
     const bool fixed = cfg.mode == T3_MODE_FIXED;
+    // to_pixels == 2: RGB8 out (row f1 fused into the pixel decoder's output stage); only the fused FIXED kernel takes it, every
+    // other framing answers 1 and the caller converts a pixel scratch with the bridge kernel
+    const bool want_rgb = to_pixels == 2;
+    if (want_rgb && !fixed) return 1;
     DecArgs a; memset(&a, 0, sizeof a);
     EmitArgs e; memset(&e, 0, sizeof e);
     a.in = (const uint8_t*)d_in; a.fail = d_fail; a.tab = api_tables(); a.fixed = fixed ? 1 : 0;
@@ -280,7 +302,9 @@ int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_r
         a.hdr_syms = 90; a.n_sym = L.n_sym;
         for (int b = 0; b < 9; ++b) { a.band_k[b] = L.band_k[b]; a.band_blocks[b] = L.band_blocks[b]; a.band_first[b] = total; a.band_off[b] = L.band_body_off[b]; total += L.band_blocks[b]; }
         use_syms = L.n_sym; n_words = n_raw;
-        const uint64_t funits = to_pixels ? 2 * n_words : n_words;
+        const uint64_t funits = want_rgb ? cap_units : to_pixels ? 2 * n_words : n_words;     // RGB: exactly the caller's pixel count (no pad pixel)
+        if (want_rgb && (cap_units > 2 * n_words || cap_units + 1 < 2 * n_words || L.interleave2d)) return 1;
+        if (want_rgb) { for (int b = 1; b < 9; ++b) if (L.band_k[b] != L.band_k[0]) return 1; }
         if (funits <= cap_units && (!to_pixels || ((uintptr_t)d_out & 15u) == 0) && getenv("T3HIP_GENERIC_DECODE") == nullptr && 9 * n_in < (1ull << 32)) {
             // a beacon is stripped first (its own pass); then the fully fused kernel where it applies, else the two-kernel path
             const uint8_t* body = (const uint8_t*)d_in; uint64_t body_bytes = 9 * n_in; uint32_t hs = L.header_syms;
@@ -291,11 +315,13 @@ int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_r
                 body = (const uint8_t*)d_b; body_bytes = L.body_syms; hs = 0;
             }
             int frc = decode_fixed_fused(body, body_bytes, hs, L, sc, d_out, funits, to_pixels, d_fail, s);
+            if (frc == 1 && want_rgb) return 1;
             if (frc == 1) frc = decode_fixed_stream(body, body_bytes, hs, cfg, L, sc, d_out, funits, to_pixels, d_fail, s);
             if (frc == T3_OK) { *n_out = funits; return T3_OK; }
             if (frc < 0) return frc;
         }
     }
+    if (want_rgb) return 1;
     a.total_blocks = total;
     const uint64_t units = to_pixels ? 2 * n_words : n_words;
     *n_out = units;

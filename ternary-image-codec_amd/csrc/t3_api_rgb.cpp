@@ -12,6 +12,7 @@
 namespace t3 {
 int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr); std::recursive_mutex& api_host_mutex();
 int api_fail_hip(hipError_t e, const char* what);
+int api_encode_rgb_fused(const void* d_rgb, uint64_t n_px, const t3_cfg* cfg, void* d_out, uint64_t cap, uint64_t* n_out, hipStream_t s);
 }  // namespace t3
 using namespace t3;
 
@@ -58,7 +59,11 @@ int t3hip_quant_to_rgb_dev(const void* d_px6, uint64_t n_px, uint8_t* d_rgb, voi
 int t3hip_encode_rgb_dev(const uint8_t* d_rgb, uint64_t n_px, const t3_cfg* cfg, void* d_out, uint64_t cap_words, uint64_t* n_out, void* stream) {
     if (!api_ready()) return T3_E_NODEVICE;
     if (!cfg || !n_out || (n_px && !d_rgb)) return T3_E_ARG;
-    void* d_q; int rc = api_scratch(4, 6 * n_px + 64, &d_q, (hipStream_t)stream); if (rc) return rc;
+    // one launch: the bridge runs inside the encoder's phase 1 (3 bytes per pixel read, no intermediate); the framings that
+    // kernel does not take (RAW mode, 2-D rows wider than 512) go through the bridge kernel and a per-stream scratch
+    int rc = api_encode_rgb_fused(d_rgb, n_px, cfg, d_out, cap_words, n_out, (hipStream_t)stream);
+    if (rc != 1) return rc;
+    void* d_q; rc = api_scratch(4, 6 * n_px + 64, &d_q, (hipStream_t)stream); if (rc) return rc;
     rc = t3hip_rgb_to_quant_dev(d_rgb, n_px, d_q, stream); if (rc) return rc;
     return t3hip_encode_frame_dev(d_q, n_px, cfg, d_out, cap_words, n_out, stream);
 }
@@ -66,8 +71,11 @@ int t3hip_decode_rgb_async(const void* d_in, uint64_t n_in, const t3_cfg* cfg, u
     if (!api_ready()) return T3_E_NODEVICE;
     if (!cfg || !d_verdict || (n_px && !d_rgb)) return T3_E_ARG;
     const uint64_t n_raw = (n_px + 1) / 2;
-    void* d_q; int rc = api_scratch(4, 12 * n_raw + 64, &d_q, (hipStream_t)stream); if (rc) return rc;
     uint64_t n_units = 0;
+    // one launch where the fused pixel decoder applies (FIXED, one k, 1-D): its output stage converts to RGB and stores 3 bytes per pixel
+    int rc = t3hip_decode_frame_async(d_in, n_in, cfg, n_raw, d_rgb, n_px, &n_units, 2, d_verdict, stream);
+    if (rc != 1) return rc;
+    void* d_q; rc = api_scratch(4, 12 * n_raw + 64, &d_q, (hipStream_t)stream); if (rc) return rc;
     rc = t3hip_decode_frame_async(d_in, n_in, cfg, n_raw, d_q, 2 * n_raw, &n_units, 1, d_verdict, stream); if (rc) return rc;
     return t3hip_quant_to_rgb_dev(d_q, n_px, d_rgb, stream);
 }

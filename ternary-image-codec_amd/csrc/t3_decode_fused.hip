@@ -92,13 +92,41 @@ __device__ __forceinline__ void fx2_queue_entry(const DecFx2Args& a, const uint3
     if (!fx2_fix_block<R>(sy.x, sy.y, y_off + bi + 9u * K * m, a.roots, a.fma_off)) atomicAdd(a.fail, 1u);
 }
 
-// D5 (pixels) for lane slot j of a tile: four triples = 52 symbols at y_off + 52 j -> 12 pixels = 72 bytes
+// D5 (pixels) for lane slot j of a tile: four triples = 52 symbols at y_off + 52 j -> 12 pixels = 72 bytes; RGB: the inverse
+// io_image.hpp bridge fused in (dequantize_ycbcr :79-84 by table, ycbcr_to_rgb :57-66 with every float step rounded on its own,
+// std::lround + clamp to 0..255 = min(trunc(x + 0.5) from zero up, 255)) -> 36 bytes
+template <bool RGB>
 __device__ __forceinline__ void fx2_pixels12(const DecFx2Args& a, const uint32_t j, const uint32_t y_off, const uint64_t unit0, const uint32_t n_here) {
     uint32_t D[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) D[i] = *T3_LP(const uint32_t, y_off + 52u * j + 4u * i);
     uint32_t o[18];
     px12_from_syms(D, o);
+    if constexpr (RGB) {
+        uint32_t w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t p = 0; p < 12; ++p) {
+            auto comp = [&](uint32_t k) -> uint32_t { return (o[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu; };
+            const uint32_t Yq = min(comp(3u * p), 242u);
+            const int cbq = max(-40, min(40, (int)(int16_t)comp(3u * p + 1u))), crq = max(-40, min(40, (int)(int16_t)comp(3u * p + 2u)));
+            const float y = (float)l8(a.dq_off + Yq);
+            const float cb = __fsub_rn((float)l8(a.dq_off + 244u + (uint32_t)(cbq + 40)), 128.0f), cr = __fsub_rn((float)l8(a.dq_off + 244u + (uint32_t)(crq + 40)), 128.0f);
+            const float r = __fadd_rn(y, __fmul_rn(1.402f, cr));
+            const float g = __fsub_rn(__fsub_rn(y, __fmul_rn(0.344136f, cb)), __fmul_rn(0.714136f, cr));
+            const float b = __fadd_rn(y, __fmul_rn(1.772f, cb));
+            const uint32_t c3[3] = {min((uint32_t)__fadd_rn(r, 0.5f), 255u), min((uint32_t)__fadd_rn(g, 0.5f), 255u), min((uint32_t)__fadd_rn(b, 0.5f), 255u)};
+#pragma unroll
+            for (uint32_t k = 0; k < 3; ++k) { const uint32_t bi = 3u * p + k; w[bi >> 2] |= c3[k] << (8u * (bi & 3u)); }
+        }
+        uint8_t* g8 = (uint8_t*)a.out + (unit0 + 12ull * j) * 3u;                    // 4-byte aligned
+        if (12u * j + 12u <= n_here) {
+            typedef uint32_t v4u __attribute__((ext_vector_type(4), aligned(4)));
+            *(v4u*)(g8) = v4u{w[0], w[1], w[2], w[3]}; *(v4u*)(g8 + 16) = v4u{w[4], w[5], w[6], w[7]}; *(uint32_t*)(g8 + 32) = w[8];
+        } else {
+#pragma unroll
+            for (uint32_t bi = 0; bi < 36; ++bi) if (12u * j + bi / 3u < n_here) g8[bi] = (uint8_t)(w[bi >> 2] >> (8u * (bi & 3u)));
+        }
+    } else {
     uint8_t* g = (uint8_t*)a.out + (unit0 + 12ull * j) * 6u;                        // 8-byte aligned
     if (12u * j + 12u <= n_here) {
         typedef uint32_t v4u __attribute__((ext_vector_type(4), aligned(8)));
@@ -110,6 +138,7 @@ __device__ __forceinline__ void fx2_pixels12(const DecFx2Args& a, const uint32_t
 #pragma unroll
         for (uint32_t hh = 0; hh < 36; ++hh)
             if (12u * j + hh / 3u < n_here) *(uint16_t*)(g + 2u * hh) = (uint16_t)(o[hh >> 1] >> (16u * (hh & 1u)));
+    }
     }
 }
 }  // namespace
@@ -126,11 +155,12 @@ __device__ __forceinline__ void fx2_pixels12(const DecFx2Args& a, const uint32_t
 // ------------------------------------------------------------------------------------------------------------------
 // pixels out: producer / consumer waves
 // ------------------------------------------------------------------------------------------------------------------
-template <int R>
+template <int R, bool RGB>
 __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_px_kernel(const DecFx2Args a) {
     constexpr uint32_t TCOP = 16, TBASE = kFx2TPx, MT = kFx2ModPx, QCAP = kFx2QCap;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     stage_tables<TCOP, TBASE, MT>(a, tid, blockDim.x);
+    if constexpr (RGB) { if (tid < 82u) *(uint32_t*)(lds + a.dq_off + 4u * tid) = ((const uint32_t*)a.dq)[tid]; }     // yd[244] | cd[84]
     __syncthreads();
 #ifdef T3_DEC_STAMPS
     uint64_t st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime(), st_t0 = st_prev, st_rt0 = __builtin_amdgcn_s_memrealtime();
@@ -207,7 +237,7 @@ __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_px_kern
                 T3D_STAMP(3);
                 const uint64_t unit0 = (uint64_t)tile * units_tile;
                 const uint32_t n_here = (uint32_t)min((uint64_t)units_tile, a.n_units > unit0 ? a.n_units - unit0 : 0ull);
-                for (uint32_t j = cw * 64u + lane; 4u * j < a.TS / 13u; j += 256u) fx2_pixels12(a, j, y_off, unit0, n_here);
+                for (uint32_t j = cw * 64u + lane; 4u * j < a.TS / 13u; j += 256u) fx2_pixels12<RGB>(a, j, y_off, unit0, n_here);
                 T3D_STAMP(4);
             }
             barrier_lds2();
@@ -281,9 +311,8 @@ __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_kernel(
     }
 }
 
-template __global__ void decode_fixed_kernel<2>(const DecFx2Args);  template __global__ void decode_fixed_px_kernel<2>(const DecFx2Args);
-template __global__ void decode_fixed_kernel<4>(const DecFx2Args);  template __global__ void decode_fixed_px_kernel<4>(const DecFx2Args);
-template __global__ void decode_fixed_kernel<6>(const DecFx2Args);  template __global__ void decode_fixed_px_kernel<6>(const DecFx2Args);
-template __global__ void decode_fixed_kernel<8>(const DecFx2Args);  template __global__ void decode_fixed_px_kernel<8>(const DecFx2Args);
+#define T3_INST_DEC(R) template __global__ void decode_fixed_kernel<R>(const DecFx2Args); template __global__ void decode_fixed_px_kernel<R, false>(const DecFx2Args); \
+    template __global__ void decode_fixed_px_kernel<R, true>(const DecFx2Args);
+T3_INST_DEC(2) T3_INST_DEC(4) T3_INST_DEC(6) T3_INST_DEC(8)
 
 }  // namespace t3

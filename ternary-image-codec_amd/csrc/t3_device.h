@@ -5,7 +5,9 @@
 
 namespace t3 {
 
-enum FrontEnd : int { FE_PIXELS = 0, FE_WORDS = 1 };
+enum FrontEnd : int { FE_PIXELS = 0, FE_WORDS = 1, FE_RGB = 2 };   // FE_RGB: RGB8 in, the io_image.hpp bridge fused into phase 1 (pipelined flow only)
+constexpr bool fe_px(int fe) { return fe == FE_PIXELS || fe == FE_RGB; }          // pixel-shaped front ends: 6 px = one lane group of 26 symbols
+constexpr int kGroupBytesRgb = 18;
 
 constexpr int kMaxWaves = 16;            // 1024-thread workgroup
 constexpr int kLdsHdr = 512;            // LDS header: 9 band rows (32 B), item prefix, ticket slot, scrambler dwords
@@ -62,6 +64,8 @@ struct EncArgs {
     uint32_t* tile_ctr;             // ticket counters [64 * class], then workgroups-finished at [64 * n_classes] (last one re-zeroes); null = static striding
     uint32_t  n_classes;            // ticket classes (<= grid)
     uint32_t  p1_wpp;               // phase 1 (pixels): waves that cover a tile (one lane = four pixel triples)
+    uint32_t  qt_off;               // FE_RGB: LDS offset of the chroma quantiser table (256 bytes: C -> Cq + 40, io_image.hpp:73-76)
+    const uint8_t* qt;              // ... and its device image
     uint64_t* dbg;                  // diagnostic stamp builds only (T3_STAMPS); null in the product
 };
 

@@ -501,7 +501,7 @@ __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t symb,
 // this tile's compute); pieces that touch the end of the data are synthesised (pad pixel OLD:730, then zero trits).
 template <int FE>
 __device__ __forceinline__ void stage_input(const EncArgs& a, uint32_t stage, uint32_t g_lo, uint32_t g_hi, uint32_t lane, uint32_t wave, uint32_t nwv) {
-    constexpr uint32_t GB = FE == FE_PIXELS ? kGroupBytes : kGroupBytesW, UB = FE == FE_PIXELS ? 6u : 9u;
+    constexpr uint32_t GB = FE == FE_PIXELS ? kGroupBytes : FE == FE_RGB ? kGroupBytesRgb : kGroupBytesW, UB = FE == FE_PIXELS ? 6u : FE == FE_RGB ? 3u : 9u;
     const uint64_t b0 = ((uint64_t)g_lo * GB) & ~15ull, b1 = (uint64_t)g_hi * GB, real = a.n_units * UB;
     const uint32_t n_chunks = (uint32_t)((b1 - b0 + 15u) >> 4);
     for (uint32_t c0 = __builtin_amdgcn_readfirstlane(wave) * 64u; c0 < n_chunks; c0 += nwv * 64u) {
@@ -522,7 +522,7 @@ __device__ __forceinline__ void stage_input(const EncArgs& a, uint32_t stage, ui
                     else val = comp == 0 ? 0u : 0xFFD8u;                          // -40 -> Cb+40 = 0
                     w[h >> 1] |= val << (16 * (h & 1));
                 }
-            } else {
+            } else {                                                              // raw words, RGB: bytes past the end read as zero (RGB black = the pad pixel)
 #pragma unroll
                 for (int h = 0; h < 16; ++h) { const uint64_t n = o + h; if (n < real) w[h >> 2] |= (uint32_t)a.in[n] << (8 * (h & 3)); }
             }
@@ -651,7 +651,22 @@ __device__ __forceinline__ void px3x2_to_sym13x8(const u16x2* c, u16x2* s) {
 // the first/last triples that belong to the neighbouring tiles (and of the up to three triples past the tile's last one).
 // Symbols [u_lo, u_hi) are produced (1-D: the tile itself; pipelined 2-D: the row segments it overlaps); symbol u lands at
 // LDS byte sym_off + (u - u_lo).
-template <int SC>
+// FE_RGB: the io_image.hpp bridge for one pixel (rgb_to_ycbcr :47-57, quantize_ycbcr :69-78): every float product and sum rounded on
+// its own (no contraction), std::lround of a non-negative value = trunc(x + 0.5) exactly (x + 0.5 is exact or rounds inside
+// the integer's unit interval), Y quantised in float (242 Y / 255 is never within 1/510 of a tie, the float error is 1e-5),
+// chroma through the 256-byte table of its quantiser.  Returns the reduced components Y < 243, Cb + 40, Cr + 40 <= 80.
+__device__ __forceinline__ void rgb_px_to_comps(const uint32_t r8, const uint32_t g8, const uint32_t b8, const uint32_t qt, uint32_t& Y, uint32_t& B, uint32_t& R) {
+    const float r = (float)r8, g = (float)g8, b = (float)b8;
+    const float y = __fadd_rn(__fadd_rn(__fmul_rn(0.299f, r), __fmul_rn(0.587f, g)), __fmul_rn(0.114f, b));
+    const float cb = __fadd_rn(__fadd_rn(__fsub_rn(__fmul_rn(-0.168736f, r), __fmul_rn(0.331264f, g)), __fmul_rn(0.5f, b)), 128.0f);
+    const float cr = __fadd_rn(__fsub_rn(__fsub_rn(__fmul_rn(0.5f, r), __fmul_rn(0.418688f, g)), __fmul_rn(0.081312f, b)), 128.0f);
+    const float Yi = fminf(truncf(__fadd_rn(y, 0.5f)), 255.0f);
+    Y = (uint32_t)__fmaf_rn(Yi, 242.0f / 255.0f, 0.5f);
+    const uint32_t Cb = min((uint32_t)__fadd_rn(cb, 0.5f), 255u), Cr = min((uint32_t)__fadd_rn(cr, 0.5f), 255u);
+    B = lds_u8(qt + Cb); R = lds_u8(qt + Cr);
+}
+
+template <int SC, int FE>
 __device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, uint32_t stage, uint64_t b0, uint32_t u_lo, uint32_t u_hi,
                                                       uint32_t lane, uint32_t wave, uint32_t nwv) {
     const uint32_t S0 = u_lo;
@@ -661,13 +676,42 @@ __device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, uint32_t
     for (uint32_t e0 = wave * 64u; t_base + 4u * e0 < t_end; e0 += nw1 * 64u) {
         const uint32_t t = t_base + 4u * (e0 + lane);
         const bool live = t < t_end;
+        u16x2 sA[13], sB[13];
+        if constexpr (FE == FE_RGB) {
+            // 12 pixels = 36 bytes = nine aligned dwords; pixel p = bytes 3p .. 3p + 2
+            const uint32_t src = stage + (uint32_t)((uint64_t)(live ? t : t_base) * 9u - b0);
+            uint32_t D[9];
+#pragma unroll
+            for (uint32_t i = 0; i < 9; ++i) D[i] = lds_u32(src + 4u * i);
+            uint32_t cY[12], cB[12], cR[12];
+#pragma unroll
+            for (uint32_t p = 0; p < 12; ++p) {
+                auto byte = [&](uint32_t k) -> uint32_t { return (D[k >> 2] >> (8u * (k & 3u))) & 0xFFu; };
+                rgb_px_to_comps(byte(3u * p), byte(3u * p + 1u), byte(3u * p + 2u), a.qt_off, cY[p], cB[p], cR[p]);
+            }
+            // pixels past the padded end of the frame are zero TRITS (Cb + 40 = 0), which no RGB value encodes: only the frame's last lanes
+            const uint64_t px0 = 3ull * t;
+            if (__builtin_amdgcn_ballot_w64(live && px0 + 12u > a.n_units_pad) != 0) {
+#pragma unroll
+                for (uint32_t p = 0; p < 12; ++p) if (px0 + p >= a.n_units_pad) { cY[p] = 0; cB[p] = 0; cR[p] = 0; }
+            }
+#pragma unroll
+            for (uint32_t pair = 0; pair < 2; ++pair) {                           // pair 0 = triples (0, 2), pair 1 = triples (1, 3)
+                u16x2 c[9];
+#pragma unroll
+                for (uint32_t m = 0; m < 3; ++m) {
+                    const uint32_t pa = 3u * pair + m, pb = pa + 6u;              // pixel of the pair's first / second triple
+                    c[3 * m] = u16x2{(uint16_t)cY[pa], (uint16_t)cY[pb]}; c[3 * m + 1] = u16x2{(uint16_t)cB[pa], (uint16_t)cB[pb]}; c[3 * m + 2] = u16x2{(uint16_t)cR[pa], (uint16_t)cR[pb]};
+                }
+                px3x2_to_sym13x8<SC>(c, pair ? sB : sA);
+            }
+        } else {
         const uint32_t src = stage + (uint32_t)((uint64_t)(live ? t : t_base) * 18u - b0);   // 8-byte aligned
         uint32_t D[18];
 #pragma unroll
         for (uint32_t i = 0; i < 9; ++i) { const u32x2 v = *T3_LDS_PTR(u32x2, src + 8u * i); D[2 * i] = v.x; D[2 * i + 1] = v.y; }
         // halves whose triple lies past the tile's last one hold stale bytes: keep them out of the range check
         const uint32_t liveA = t + 2u < t_end ? 0xFFFFFFFFu : 0x0000FFFFu, liveB = (t + 1u < t_end ? 0x0000FFFFu : 0u) | (t + 3u < t_end ? 0xFFFF0000u : 0u);
-        u16x2 sA[13], sB[13];
 #pragma unroll
         for (uint32_t pair = 0; pair < 2; ++pair) {                               // pair 0 = triples (0, 2), pair 1 = triples (1, 3)
             u16x2 h[9], c[9];
@@ -689,6 +733,7 @@ __device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, uint32_t
                 }
             }
             px3x2_to_sym13x8<SC>(c, pair ? sB : sA);
+        }
         }
         // 16-bit pieces of the 52 output bytes (low half: first triple of the pair, high half: second):
         //   E_j = (s_2j, s_2j+1) of triples 0/2;  O_j = (s_2j+1, s_2j+2) of triples 1/3;  X = (s_12 of 0/2, s_0 of 1/3)
@@ -742,7 +787,8 @@ __device__ __forceinline__ void barrier_input(uint32_t younger) {
 // 640-thread bound so that two workgroups share a CU); RSEL = 0 handles mixed k with a wave-uniform switch.
 template <int FE, bool IL, int RSEL>
 __device__ __forceinline__ void encode_body(const EncArgs& a) {
-    constexpr uint32_t GS = FE == FE_PIXELS ? kGroupSyms : kGroupSymsW;      // symbols per lane group
+    constexpr uint32_t GS = fe_px(FE) ? kGroupSyms : kGroupSymsW;      // symbols per lane group
+    constexpr uint32_t GBf = FE == FE_PIXELS ? kGroupBytes : FE == FE_RGB ? kGroupBytesRgb : kGroupBytesW;
     constexpr int SH = RSEL != 0 ? 2 : 3;                                     // symbol pre-scale: 4-byte T entries (MFMA) / 8-byte LUT entries
     const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
     const uint32_t TS = 9u * a.Lq;
@@ -778,6 +824,8 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     for (uint32_t i = tid * 16u; i < a.lut_bytes; i += nthr * 16u)
         *(uint4*)(lds + (RSEL == 1 ? kLdsHdrUep : kLdsHdr) + i) = *(const uint4*)((const uint8_t*)a.lut_img + i);
 
+    if constexpr (FE == FE_RGB) { if (tid < 64u) *(uint32_t*)(lds + a.qt_off + 4u * tid) = ((const uint32_t*)a.qt)[tid]; }
+
     if (blockIdx.x == 0 && a.frame_out) {                                    // header symbols + zero tail (OLD:1159-1167)
         if (tid == 0) {                                                      // constant indices only (see above)
 #pragma unroll
@@ -805,7 +853,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 
     // first lane group whose input a tile starting at stream symbol S needs (pixels: the packed converter starts at a
     // multiple of 4 triples = 2 groups)
-    auto first_group = [](uint32_t S) -> uint32_t { return FE == FE_PIXELS ? ((S / 13u) & ~3u) / 2u : S / GS; };
+    auto first_group = [](uint32_t S) -> uint32_t { return fe_px(FE) ? ((S / 13u) & ~3u) / 2u : S / GS; };
     // pre-interleave symbols [lo, hi) a tile starting at S needs: itself in 1-D; in 2-D the whole row segments it overlaps
     // (the map stays inside a row segment, OLD:750-780) plus its own positions past the end of the stream (identity)
     auto need_lo = [&](uint32_t S) -> uint32_t { return (IL && S < a.n_sym) ? il_row_start(S, a) : S; };
@@ -830,7 +878,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     // a class's tiles are cls + NC j: j < wgc first tiles (= blockIdx), wgc <= j < 2 wgc second tiles (static too), then tickets
     // the input of tile i+1 is requested at the top of tile i into the other stage buffer, by the waves that phase 1 (pixels)
     // leaves idle: issuing the LDS-DMA costs ~400 cycles per KiB piece and would otherwise sit between the two phases
-    const uint32_t w0 = FE == FE_PIXELS ? min(a.p1_wpp, nwv - 1u) : min((TS / GS + 2u + 63u) / 64u, nwv - 1u);   // raw words: waves that hold a lane group of the tile
+    const uint32_t w0 = fe_px(FE) ? min(a.p1_wpp, nwv - 1u) : min((TS / GS + 2u + 63u) / 64u, nwv - 1u);   // raw words: waves that hold a lane group of the tile
     // Tickets are drawn by lane 0 of the LAST wave: the compiler turns the atomic into its wave-aggregated form, which reads the
     // result back at once (s_waitcnt vmcnt(0): the atomic's round trip plus the acknowledgement of the wave's stores of the
     // previous tile).  On thread 0 that stall sat in front of phase 1's conversion, on the critical path of every tile; the
@@ -863,7 +911,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             T3_STAMP(4);
 #ifndef T3_ABL_NO_P1
             const uint32_t u_lo = need_lo(S0), u_hi = need_hi(S0);
-            if constexpr (FE == FE_PIXELS) convert_pixels_packed<(1 << SH)>(a, stage, ((uint64_t)first_group(u_lo) * kGroupBytes) & ~15ull, u_lo, u_hi, lane, vw, nwv);
+            if constexpr (fe_px(FE)) convert_pixels_packed<(1 << SH), FE>(a, stage, ((uint64_t)first_group(u_lo) * GBf) & ~15ull, u_lo, u_hi, lane, vw, nwv);
             else convert_groups<FE, false, SH>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, vw * 64u + lane, nthr);
 #endif
             T3_STAMP(5);                                                      // (diagnostic) this wave's conversion
@@ -1034,7 +1082,7 @@ __global__ __launch_bounds__(1024) void encode_kernel_mixed(const EncArgs a) { e
     template __global__ void encode_kernel_k<FE, IL, 2>(const EncArgs); template __global__ void encode_kernel_k<FE, IL, 4>(const EncArgs); \
     template __global__ void encode_kernel_k<FE, IL, 6>(const EncArgs); template __global__ void encode_kernel_k<FE, IL, 8>(const EncArgs); \
     template __global__ void encode_kernel_mixed<FE, IL>(const EncArgs); template __global__ void encode_kernel_uep<FE, IL>(const EncArgs);
-T3_INST_K(FE_PIXELS, false) T3_INST_K(FE_PIXELS, true) T3_INST_K(FE_WORDS, false) T3_INST_K(FE_WORDS, true)
+T3_INST_K(FE_PIXELS, false) T3_INST_K(FE_PIXELS, true) T3_INST_K(FE_WORDS, false) T3_INST_K(FE_WORDS, true) T3_INST_K(FE_RGB, false) T3_INST_K(FE_RGB, true)
 
 // ---------------------------------------------------------------------------------------------------------
 // beacon insertion pass (OLD:1118-1141): framed[q] = beacon symbol at slot `slot` of every period-th word, else

@@ -613,6 +613,37 @@ def test_rgb_frame_encode_decode(t3, orc, gpu, npx):
 
 
 @pytest.mark.gpu
+def test_rgb_fused_all_colours(t3, orc, gpu):
+    """Row f1 fused into the codec kernels, exhaustively: a 4096 x 4096 "frame" holding every one of the 2^24 RGB values goes
+    through the encoder's fused front end (3 bytes per pixel in, phase 1 converts) and must equal the oracle's bridge followed by
+    its encoder, byte for byte; decoded with RGB out (the decoder's fused output stage) it must equal the oracle's quantisation
+    round trip.  (Parity of the bridge itself against the reference: unpinned -- io_image.hpp does not compile, DESIGN.md.)"""
+    import torch
+    n = 1 << 24
+    v = np.arange(n, dtype=np.uint32)
+    rgb = np.empty(3 * n, np.uint8); rgb[0::3] = v & 255; rgb[1::3] = (v >> 8) & 255; rgb[2::3] = v >> 16
+    rng = np.random.default_rng(5); perm = rng.permutation(n)                  # every colour once, in random order (neighbours differ in all channels)
+    rgb = rgb.reshape(n, 3)[perm].reshape(-1).copy()
+    cfg, ocfg = both(gpu, dict(profile=2, uep=2), mode=1)
+    q = orc.rgb_to_quant(rgb)
+    rc, want = orc.encode_frame(q, ocfg, cap=n + 64); assert rc == 0
+    s = torch.cuda.current_stream().cuda_stream
+    d_rgb = torch.from_numpy(rgb).cuda()
+    n_cap = t3.encoded_words(n // 2, cfg)
+    d_out = torch.zeros(n_cap * 9 + 64, dtype=torch.uint8, device="cuda")
+    assert t3.encode_rgb_dev(d_rgb.data_ptr(), n, cfg, d_out.data_ptr(), n_cap, s) == len(want)
+    torch.cuda.synchronize()
+    got = d_out[: 9 * len(want)].cpu().numpy()
+    assert np.array_equal(got, np.asarray(want).reshape(-1)), np.flatnonzero(got != np.asarray(want).reshape(-1))[:8]
+    d_back = torch.zeros(3 * n + 64, dtype=torch.uint8, device="cuda"); ver = torch.full((2,), 9, dtype=torch.int32, device="cuda")
+    t3.decode_rgb_async(d_out.data_ptr(), len(want), cfg, n, d_back.data_ptr(), ver.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert ver.cpu().numpy().tolist() == [0, 0]
+    assert np.array_equal(d_back[: 3 * n].cpu().numpy(), np.asarray(orc.quant_to_rgb(q)).reshape(-1))
+    assert int(d_back[3 * n:].sum().item()) == 0                               # nothing written past the frame
+
+
+@pytest.mark.gpu
 def test_host_api_two_threads(gpu, orc):
     """The std::vector-shaped entry points share one stream and two scratch slots inside the library; two caller threads encoding
     and decoding DIFFERENT frames of different sizes at the same time must each get their own frame's bytes (the library holds
