@@ -136,6 +136,36 @@ def end_to_end(t3, px, cfg, fenc_bad, reps=3):
             "note": "t3hip_encode_frame / t3hip_decode_frame on pageable host buffers (what the std::vector API binds): upload, kernels, download, sync; best of %d" % reps}
 
 
+def rgb_path(t3, orc, torch, dev, cfg, fcfg, stream, n=60, warm=150):
+    """The same frame geometry entering and leaving as RGB8 (BASELINE: "synthetic 8K RGB frames"): the io_image.hpp bridge fused into
+    the encoder's phase 1 and the decoder's output stage (row f1; parity of the bridge against a reference build is UNPINNED --
+    that header does not compile -- it is exact against the oracle's restatement on all 2^24 colours).  HIP events, sustained clock."""
+    rgb = torch.from_numpy(orc.lcg_rgb(NPX, SEED0)).to(dev)
+    n_enc = t3.encoded_words(NPX // 2, cfg); n_fenc = t3.encoded_words(NPX // 2, fcfg)
+    out = torch.zeros(n_enc * 9 + 64, dtype=torch.uint8, device=dev); fout = torch.zeros(n_fenc * 9 + 64, dtype=torch.uint8, device=dev)
+    back = torch.zeros(3 * NPX + 64, dtype=torch.uint8, device=dev); ver = torch.zeros(2, dtype=torch.int32, device=dev)
+    t3.encode_rgb_dev(rgb.data_ptr(), NPX, fcfg, fout.data_ptr(), n_fenc, stream)
+    L = t3.plan(NPX // 2, fcfg)
+    t3.inject_errors_dev(fout.data_ptr(), L.header_syms, L.body_syms // 26, 999, 3, stream)
+
+    def timed(f):
+        for _ in range(warm): f()
+        torch.cuda.synchronize()
+        e0, e1 = t3.Event(), t3.Event()
+        e0.record(stream)
+        for _ in range(n): f()
+        e1.record(stream)
+        return e0.elapsed_ms(e1) / n
+    te = timed(lambda: t3.encode_rgb_dev(rgb.data_ptr(), NPX, cfg, out.data_ptr(), n_enc, stream))
+    td = timed(lambda: t3.decode_rgb_async(fout.data_ptr(), n_fenc, fcfg, NPX, back.data_ptr(), ver.data_ptr(), stream))
+    assert ver.cpu().tolist() == [0, 0]
+    eb, db = 3 * NPX + 9 * n_enc, 9 * n_fenc + 3 * NPX
+    return {"encode_ms": round(te, 4), "decode_ms": round(td, 4), "encode_mpix_s": round(NPX / te / 1e3, 1), "decode_mpix_s": round(NPX / td / 1e3, 1),
+            "encode_roofline_frac": round(eb / (te * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "decode_roofline_frac": round(db / (td * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes": {"encode": eb, "decode": db},
+            "note": "RGB8 in / out, bridge fused into the codec kernels (one launch per direction; decode stream carries 0..3 errors per block); bound: VALU (float conversion), not HBM; bridge parity unpinned against the reference, exact against the oracle on all 2^24 colours"}
+
+
 def self_launch(args, argv):
     """--gpus N > 1 without a launcher: start the N ranks as a child process tree.  Nothing here has touched the GPU."""
     with socket.socket() as sk:
@@ -157,6 +187,7 @@ def main():
     ap.add_argument("--frames-per-rank", type=int, default=8, help="distinct frames resident per rank (BASELINE configs[3]: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-rgb", action="store_true", help="skip the RGB-in / RGB-out side measurement")
     ap.add_argument("--encode-only", action="store_true", help="profiling aid: skip decode + index in the loop")
     ap.add_argument("--overlap-record", action="store_true", help="index record on a second HIP stream beside the decode (round 1's default; the round-2 decoder leaves the CRC kernel no registers to run beside it, so the record now follows on the main stream)")
     ap.add_argument("--serial", action="store_true", help="(default now) index record on the main stream")
@@ -371,6 +402,8 @@ def main():
                                   "frac": round(dec_bytes / (dec_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc("pmc_decode_latest.json"),
                                   "algorithmic_bytes_per_launch": dec_bytes, "launch_ms": round(dec_avg, 4)}
     if world == 1 and not args.no_verify:                  # reported beside the line, on rank 0 at N=1 only
+        if not args.encode_only and not args.no_rgb:
+            out["rgb_path"] = rgb_path(t3, orc, torch, dev, cfg, fcfg, stream)
         if not args.no_end_to_end and not args.encode_only:
             out["end_to_end"] = end_to_end(t3, px_host[0], cfg, d_fenc[0][: n_fenc * 9].cpu().numpy().reshape(-1, 9))
         if not args.no_cpu_baseline:

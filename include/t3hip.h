@@ -16,7 +16,10 @@
  *   - functions return T3_OK (0) or a negative T3_E_* code.  The reference's `bool`
  *     results map to: true = T3_OK, false = T3_E_HEADER / T3_E_RS / T3_E_ARG.
  *   - *_dev entry points take DEVICE pointers and a hipStream_t (as void*), never
- *     allocate caller-visible memory and never synchronise unless documented.
+ *     allocate caller-visible memory and never synchronise unless documented.  Device buffers of the profile
+ *     encode / decode entry points must be 16-byte aligned (T3_E_ARG otherwise; RAW mode and the pack / unpack,
+ *     subword, RGB-bridge and CRC entry points take any alignment): consecutive frames packed into one buffer
+ *     (9 * n_words bytes each) start on a 16-byte boundary only if the caller pads them.
  *   - there is no CPU fallback: compute entry points fail with T3_E_NODEVICE when
  *     no gfx950 device is usable.  Pure-metadata calls (plan, tables, header) are host-only.
  */
@@ -106,11 +109,23 @@ typedef struct t3_frame_record {
     uint8_t  pad_[8];
 } t3_frame_record;
 
-/* ---- lifecycle --------------------------------------------------------------- */
+/* ---- lifecycle ---------------------------------------------------------------
+ * A context = one GPU's stream, tables and scratch.  t3hip_init creates the process DEFAULT context on `device` (idempotent for
+ * the same device; T3_E_ARG for another one while it exists: t3hip_shutdown first, or use t3hip_create).  A host that drives
+ * several GPUs from one process -- the reference's language has no process-per-GPU launcher -- creates one context per device
+ * (t3hip_create) and binds each of its worker threads to one with t3hip_use (thread-local; also makes that device current for
+ * HIP).  Every entry point of this header works on the calling thread's context: the one given to t3hip_use, else the default.
+ * Contexts are independent: two threads on two contexts never share a stream, a scratch buffer or a lock. */
+typedef struct t3hip_ctx t3hip_ctx;
 int         t3hip_device_count(void);
-int         t3hip_init(int device);              /* binds the calling process to one GPU */
-int         t3hip_shutdown(void);
-int         t3hip_is_ready(void);                /* 1 after a successful t3hip_init      */
+int         t3hip_init(int device);              /* the process default context           */
+int         t3hip_shutdown(void);                /* destroys the default context          */
+int         t3hip_is_ready(void);                /* 1 when the calling thread has a usable context */
+int         t3hip_create(int device, t3hip_ctx** out);
+int         t3hip_destroy(t3hip_ctx* ctx);       /* not the default context (that is t3hip_shutdown's) */
+int         t3hip_use(t3hip_ctx* ctx);           /* bind the calling thread; NULL = back to the default */
+t3hip_ctx*  t3hip_current(void);                 /* the calling thread's context (NULL if none)   */
+int         t3hip_ctx_device(const t3hip_ctx* ctx);   /* its device index (-1 if none); NULL = current */
 const char* t3hip_strerror(int code);
 const char* t3hip_last_hip_error(void);
 const char* t3hip_version(void);
@@ -299,6 +314,10 @@ int t3hip_encode_rgb_dev(const uint8_t* d_rgb, uint64_t n_px, const t3_cfg* cfg,
                          uint64_t* n_out, void* stream);
 int t3hip_decode_rgb_async(const void* d_in9, uint64_t n_in, const t3_cfg* cfg, uint64_t n_px, uint8_t* d_rgb,
                            uint32_t* d_verdict, void* stream);
+
+/* ---- measurement aid: a plain streaming kernel (16 bytes per lane, four loads in flight) that reads n_read and writes n_write
+ * bytes: the part's ceiling for a codec launch's byte volumes (profiles/copy_ceiling.py).  16-byte aligned buffers. */
+int t3hip_diag_stream_copy_dev(const void* d_src, uint64_t n_read, void* d_dst, uint64_t n_write, int blocks_per_cu /* < 0: non-temporal */, void* stream);
 
 /* ---- timing helper: HIP events on the caller's stream -------------------------------- */
 int t3hip_event_create(void** ev);

@@ -131,6 +131,29 @@ def is_ready():
     return bool(lib().t3hip_is_ready())
 
 
+class Context:
+    """One GPU's context (t3hip_create): own stream, tables and scratch.  `use()` binds the CALLING THREAD to it -- every call of this
+    module made by that thread then runs on it -- `use_default()` goes back to the process default (init())."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _chk(lib().t3hip_create(C.c_int(device), C.byref(self.h)), "t3hip_create(%d)" % device)
+
+    def use(self):
+        _chk(lib().t3hip_use(self.h), "t3hip_use")
+
+    @staticmethod
+    def use_default():
+        _chk(lib().t3hip_use(C.c_void_p()), "t3hip_use(NULL)")
+
+    def device(self):
+        return lib().t3hip_ctx_device(self.h)
+
+    def destroy(self):
+        if self.h:
+            _chk(lib().t3hip_destroy(self.h), "t3hip_destroy"); self.h = C.c_void_p()
+
+
 def _chk(rc, where):
     if rc != OK:
         raise T3Error(rc, where)

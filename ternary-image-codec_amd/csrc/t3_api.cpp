@@ -39,8 +39,16 @@ struct Ctx {
     // launch -> download -> synchronise sequence (two caller threads otherwise interleave on the stream and overwrite, or free,
     // each other's scratch).  Recursive: some of them are built from others.
     std::recursive_mutex host_mu;
+    void* slot[48] = {};                                  // device / pinned objects of the other translation units (api_slot), freed by their owners
 };
-Ctx g;
+// One context per GPU.  t3hip_init creates the process default; t3hip_create more (one per device for a host that drives a whole
+// node from one process); t3hip_use binds the calling thread to one of them (thread-local), every entry point works on the
+// calling thread's context.  `g` below IS that context.
+Ctx g_null;                                               // stands in while no context exists: ready == false
+Ctx* g_def = nullptr;
+thread_local Ctx* tl_cur = nullptr;
+inline Ctx* cur_ctx() { return tl_cur ? tl_cur : (g_def ? g_def : &g_null); }
+#define g (*cur_ctx())
 
 int fail_hip(hipError_t e, const char* what) { g.hip_err = std::string(what) + ": " + hipGetErrorString(e); return T3_E_HIP; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail_hip(e_, #x); } while (0)
@@ -50,6 +58,8 @@ const int kOfIndex[4] = {24, 22, 20, 18};
 
 int scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr) {
     if (slot >= 2) {                                     // per stream: two streams may have frames in flight at the same time
+        static thread_local char per_thread_key;          // hipStreamPerThread is one handle value but a different stream in every thread
+        if (s == hipStreamPerThread) s = (hipStream_t)(void*)&per_thread_key;
         auto& e = g.sbuf[std::make_pair(slot, s)];
         if (bytes > e.second) {
             if (e.first) HIPCHK(hipFree(e.first));       // synchronises with whatever still reads it
@@ -164,7 +174,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     // pick q: tile = 9*Lk*q stream symbols; band b then owns Lk*q/k_b blocks
     double best_score = -1; uint32_t best_q = 0;
     for (int pass = 0; pass < 2 && !best_q; ++pass) {
-        const uint32_t budget = pass == 0 ? 53u * 1024u : 160u * 1024u;     // <= 53 KiB: three workgroups per CU
+        const uint32_t budget = pass == 0 ? 42u * 1280u : 160u * 1024u;     // LDS comes in 1280-byte units, 128 per CU (measured, t3_api_decode.cpp): <= 42 units = three workgroups per CU
         static const uint32_t force_q = getenv("T3HIP_FORCE_Q") ? (uint32_t)atoi(getenv("T3HIP_FORCE_Q")) : 0u;   // measurement knob
         for (uint32_t q = 1; q <= 4096; ++q) {
             if (force_q && q != force_q && q < force_q) continue;
@@ -258,13 +268,15 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
 
 int launch_fn(const void* fn, const EncLaunch& e, hipStream_t s) {
     // persistent grid = what is actually resident: workgroups/CU from the occupancy query (VGPR, LDS and wave limits)
-    static std::map<std::pair<const void*, uint64_t>, int> occ_cache;
+    static std::map<std::pair<const void*, uint64_t>, int> occ_cache; static std::mutex occ_mu;   // shared by every context (one device type)
+    std::lock_guard<std::mutex> occ_lk(occ_mu);
     const auto key = std::make_pair(fn, (uint64_t)e.block << 32 | e.a.lds_bytes);
     auto it = occ_cache.find(key);
     if (it == occ_cache.end()) {
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int occ = 1;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)e.block, e.a.lds_bytes));
+        occ = std::min<int>(occ, (int)(128u / ((e.a.lds_bytes + 1279u) / 1280u)));   // LDS is handed out in 1280-byte units, 128 per CU (t3_api_decode.cpp)
         it = occ_cache.emplace(key, std::max(1, occ)).first;
     }
     static const int occ_cap = getenv("T3HIP_MAX_WG_PER_CU") ? atoi(getenv("T3HIP_MAX_WG_PER_CU")) : 0;   // measurement knob
@@ -278,11 +290,13 @@ int launch_fn(const void* fn, const EncLaunch& e, hipStream_t s) {
 #endif
     {   // dynamic tile tickets: a zeroed counter pair per stream (launches on one stream are ordered; the kernel re-zeroes it)
         static const bool off = getenv("T3HIP_STATIC_TILES") != nullptr;      // measurement knob
+        bool sl_force_static = false;
         constexpr uint32_t kSlots = 64, kSlotWords = 64 * 9;                  // 8 class counters + 1 done counter, 256 B apart
         if (!g.d_ctr) { HIPCHK(hipMalloc((void**)&g.d_ctr, kSlots * kSlotWords * 4)); HIPCHK(hipMemset(g.d_ctr, 0, kSlots * kSlotWords * 4)); }
+        if (s == hipStreamPerThread) sl_force_static = true;                   // one handle value, a different real stream per thread: no shared ticket slot
         auto sl = g.ctr_slot.find(s);
         if (sl == g.ctr_slot.end() && g.ctr_slot.size() < kSlots) sl = g.ctr_slot.emplace(s, (uint32_t)g.ctr_slot.size()).first;
-        const_cast<EncLaunch&>(e).a.tile_ctr = (off || sl == g.ctr_slot.end()) ? nullptr : g.d_ctr + kSlotWords * sl->second;
+        const_cast<EncLaunch&>(e).a.tile_ctr = (off || sl_force_static || sl == g.ctr_slot.end()) ? nullptr : g.d_ctr + kSlotWords * sl->second;
         const_cast<EncLaunch&>(e).a.n_classes = std::min<uint32_t>(8u, grid);
     }
     void* args[] = {(void*)&e.a};
@@ -335,7 +349,7 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 // chroma quantiser of the fused RGB front end: C -> clamp(lround((C - 128) * (40.0 / 128.0)), -40, 40) + 40 (io_image.hpp:73-76), the
 // reference's own double expression tabulated on the host
 int rgb_quant_table(const uint8_t** out) {
-    static uint8_t* d_qt = nullptr;
+    uint8_t*& d_qt = (uint8_t*&)g.slot[47];
     if (!d_qt) {
         uint8_t t[256];
         for (int c = 0; c < 256; ++c) { long v = lround((c - 128) * (40.0 / 128.0)); v = v < -40 ? -40 : (v > 40 ? 40 : v); t[c] = (uint8_t)(v + 40); }
@@ -348,7 +362,8 @@ int rgb_quant_table(const uint8_t** out) {
 int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, void* d_out, uint64_t cap_words, uint64_t* n_out, hipStream_t s) {
     if (!g.ready) return T3_E_NODEVICE;
     if (fe == FE_RGB && cfg && n_out && d_in && !aligned16(d_in)) return 1;      // the bridge kernel takes any alignment
-    if (!cfg || !n_out || (n_units && !d_in) || !aligned16(d_in) || !aligned16(d_out)) return T3_E_ARG;
+    const bool raw_mode = cfg && cfg->profile == T3_RAW_MODE;                       // RAW: a copy or the pack kernel, any alignment
+    if (!cfg || !n_out || (n_units && !d_in) || (!raw_mode && (!aligned16(d_in) || !aligned16(d_out)))) return T3_E_ARG;
     const uint64_t n_raw = fe_px(fe) ? (n_units + 1) / 2 : n_units;
     t3_layout L; int rc = plan(n_raw, *cfg, L); if (rc != T3_OK) return rc;
     *n_out = L.out_words;
@@ -430,45 +445,99 @@ extern "C" {
 
 int t3hip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
-int t3hip_init(int device) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (g.ready && g.dev == device) return T3_OK;
+static int ctx_init(Ctx* c, int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return T3_E_NODEVICE;
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t p; HIPCHK(hipGetDeviceProperties(&p, device));
-    if (std::string(p.gcnArchName).find("gfx950") == std::string::npos) { g.hip_err = std::string("not a gfx950 device: ") + p.gcnArchName; return T3_E_NODEVICE; }
-    g.n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-    HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    if (std::string(p.gcnArchName).find("gfx950") == std::string::npos) { c->hip_err = std::string("not a gfx950 device: ") + p.gcnArchName; return T3_E_NODEVICE; }
+    c->n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const Field& F = field();
-    HIPCHK(hipMalloc((void**)&g.d_tab, sizeof(RsTables)));
-    HIPCHK(hipMemcpy(g.d_tab, &F.t, sizeof(RsTables), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&c->d_tab, sizeof(RsTables)));
+    HIPCHK(hipMemcpy(c->d_tab, &F.t, sizeof(RsTables), hipMemcpyHostToDevice));
     for (int i = 0; i < 4; ++i) for (int m = 0; m < 2; ++m) {
         uint8_t P[24 * 8]; rs_parity_matrix(kOfIndex[i], m, P);
-        HIPCHK(hipMalloc((void**)&g.d_P[i][m], sizeof P));
-        HIPCHK(hipMemcpy(g.d_P[i][m], P, sizeof P, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&c->d_P[i][m], sizeof P));
+        HIPCHK(hipMemcpy(c->d_P[i][m], P, sizeof P, hipMemcpyHostToDevice));
     }
-    HIPCHK(hipMalloc((void**)&g.d_flag, 64));
-    int rc = t3::decode_init(g.d_tab); if (rc) return rc;
-    g.dev = device; g.ready = true;
+    HIPCHK(hipMalloc((void**)&c->d_flag, 64));
+    Ctx* const prev = tl_cur; tl_cur = c;                 // the decode half builds its tables into the context it finds current
+    const int rc = t3::decode_init(c->d_tab);
+    tl_cur = prev;
+    if (rc) return rc;
+    c->dev = device; c->ready = true;
     return T3_OK;
+}
+static void ctx_teardown(Ctx* c) {
+    Ctx* const prev = tl_cur; tl_cur = c;
+    (void)hipSetDevice(c->dev);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : c->luts) { (void)hipFree(kv.second.d_img); if (kv.second.d_afrag) (void)hipFree(kv.second.d_afrag); }
+    c->luts.clear();
+    for (auto& kv : c->sbuf) if (kv.second.first) (void)hipFree(kv.second.first);
+    c->sbuf.clear();
+    for (int i = 0; i < 4; ++i) { if (c->buf[i]) (void)hipFree(c->buf[i]); c->buf[i] = nullptr; c->cap[i] = 0; for (int m = 0; m < 2; ++m) { (void)hipFree(c->d_P[i][m]); c->d_P[i][m] = nullptr; } }
+    t3::decode_shutdown();                                // frees what the other translation units keep in this context's slots
+    for (void*& p : c->slot) p = nullptr;
+    if (c->d_ctr) { (void)hipFree(c->d_ctr); c->d_ctr = nullptr; } c->ctr_slot.clear();
+    (void)hipFree(c->d_tab); (void)hipFree(c->d_flag); (void)hipStreamDestroy(c->stream);
+    c->ready = false; c->dev = -1;
+    tl_cur = prev == c ? nullptr : prev;
+}
+static std::mutex g_ctx_mu;
+
+int t3hip_init(int device) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (g_def && g_def->ready) return g_def->dev == device ? T3_OK : T3_E_ARG;      // the default context stays on its device: t3hip_shutdown first, or t3hip_create
+    if (!g_def) g_def = new Ctx();
+    const int rc = ctx_init(g_def, device);
+    if (rc) { g_null.hip_err = g_def->hip_err; delete g_def; g_def = nullptr; }
+    return rc;
 }
 
 int t3hip_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (!g.ready) return T3_OK;
-    (void)hipDeviceSynchronize();
-    for (auto& kv : g.luts) (void)hipFree(kv.second.d_img);
-    g.luts.clear();
-    for (auto& kv : g.sbuf) if (kv.second.first) (void)hipFree(kv.second.first);
-    g.sbuf.clear();
-    for (int i = 0; i < 4; ++i) { if (g.buf[i]) (void)hipFree(g.buf[i]); g.buf[i] = nullptr; g.cap[i] = 0; for (int m = 0; m < 2; ++m) { (void)hipFree(g.d_P[i][m]); g.d_P[i][m] = nullptr; } }
-    t3::decode_shutdown();
-    if (g.d_ctr) { (void)hipFree(g.d_ctr); g.d_ctr = nullptr; } g.ctr_slot.clear();
-    (void)hipFree(g.d_tab); (void)hipFree(g.d_flag); (void)hipStreamDestroy(g.stream);
-    g.ready = false; g.dev = -1;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (!g_def) return T3_OK;
+    if (g_def->ready) ctx_teardown(g_def);
+    if (tl_cur == g_def) tl_cur = nullptr;
+    delete g_def; g_def = nullptr;
     return T3_OK;
 }
+
+int t3hip_create(int device, t3hip_ctx** out) {
+    if (!out) return T3_E_ARG;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    int prev_dev = -1; (void)hipGetDevice(&prev_dev);
+    Ctx* c = new Ctx();
+    const int rc = ctx_init(c, device);
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
+    if (rc) { g_null.hip_err = c->hip_err; delete c; return rc; }
+    *out = (t3hip_ctx*)c;
+    return T3_OK;
+}
+int t3hip_destroy(t3hip_ctx* h) {
+    if (!h) return T3_OK;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    Ctx* c = (Ctx*)h;
+    if (c == g_def) return T3_E_ARG;                      // the default context goes with t3hip_shutdown
+    int prev_dev = -1; (void)hipGetDevice(&prev_dev);
+    if (c->ready) ctx_teardown(c);
+    if (tl_cur == c) tl_cur = nullptr;
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
+    delete c;
+    return T3_OK;
+}
+int t3hip_use(t3hip_ctx* h) {
+    Ctx* c = (Ctx*)h;
+    if (c && !c->ready) return T3_E_ARG;
+    tl_cur = c;
+    Ctx* eff = cur_ctx();
+    if (eff->ready) HIPCHK(hipSetDevice(eff->dev));
+    return T3_OK;
+}
+t3hip_ctx* t3hip_current(void) { Ctx* c = cur_ctx(); return c->ready ? (t3hip_ctx*)c : nullptr; }
+int t3hip_ctx_device(const t3hip_ctx* h) { const Ctx* c = h ? (const Ctx*)h : cur_ctx(); return c->ready ? c->dev : -1; }
 int t3hip_is_ready(void) { return g.ready ? 1 : 0; }
 const char* t3hip_strerror(int c) {
     switch (c) {
@@ -601,4 +670,5 @@ uint32_t* api_flag() { return g.d_flag; }
 RsTables* api_tables() { return g.d_tab; }
 int api_n_cu() { return g.n_cu; }
 std::recursive_mutex& api_host_mutex() { return g.host_mu; }
+void*& api_slot(int id) { return g.slot[id]; }
 }  // namespace t3

@@ -19,22 +19,32 @@
 namespace t3 {
 int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr);
 int api_fail_hip(hipError_t e, const char* what); uint32_t* api_flag(); RsTables* api_tables(); int api_n_cu(); std::recursive_mutex& api_host_mutex();
+void*& api_slot(int id);          // per-context object slots (t3_api.cpp): this file owns 0..31
 }  // namespace t3
 using namespace t3;
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return api_fail_hip(e_, #x); } while (0)
 
 namespace {
-uint32_t* d_zpow = nullptr;     // CRC "append 2^j zero bytes" operators
-uint32_t* d_crc_acc = nullptr;  // [0] xor accumulator, [1] symbol sum
-uint32_t* d_crc_afrag = nullptr; // bit-matrix slices of the matrix-core CRC (t3_crc_mfma.hip)
-FxTables* d_fxtab = nullptr;    // field tables of the fused FIXED decoder
-uint32_t* d_synd_lut[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t synd_lut_bytes[4] = {0, 0, 0, 0};   // per k index
-uint8_t* d_fma = nullptr;       // fma[x][y][a] = a + x y: one table read per multiply-accumulate of the corrector
-uint32_t* d_roots[4] = {nullptr, nullptr, nullptr, nullptr};   // per k index: the Chien search (OLD:611-623) of every locator, tabulated
-uint32_t* d_synd_afrag[4] = {nullptr, nullptr, nullptr, nullptr};   // per k index: A operand of the syndrome MFMA (t3_host.hpp build_mfma_syndrome)
-uint32_t* d_synd_T = nullptr, *d_synd_T16 = nullptr;   // descramble + trit expansion table of the syndrome MFMA (32 / 16 bank copies)
-uint8_t* d_fx2_small = nullptr; // log / exp / inverse byte tables of the fused decoders
+// Device tables and pinned mailboxes of the decode half live in the calling thread's context (one per GPU, t3_api.cpp), in
+// numbered slots; the names below resolve to the current context at every use.
+#define T3_SLOT(T, id) (*(T*)&api_slot(id))
+#define d_zpow        T3_SLOT(uint32_t*, 0)     // CRC "append 2^j zero bytes" operators
+#define d_crc_acc     T3_SLOT(uint32_t*, 1)     // [0] xor accumulator, [1] symbol sum
+#define d_crc_afrag   T3_SLOT(uint32_t*, 2)     // bit-matrix slices of the matrix-core CRC (t3_crc_mfma.hip)
+#define d_fxtab       T3_SLOT(FxTables*, 3)     // field tables of the two-kernel FIXED decoder
+#define d_fma         T3_SLOT(uint8_t*, 4)      // fma[x][y][a] = a + x y: one table read per multiply-accumulate of the corrector
+#define d_synd_T      T3_SLOT(uint32_t*, 5)     // descramble + trit expansion table of the syndrome MFMA, 32 bank copies
+#define d_synd_T16    T3_SLOT(uint32_t*, 6)     // ... 16 bank copies
+#define d_fx2_small   T3_SLOT(uint8_t*, 7)      // log / exp / inverse byte tables + fold tables of the fused decoders
+#define d_rgb_dq      T3_SLOT(uint8_t*, 8)      // dequantiser tables of the fused RGB output stage
+#define h_mail        T3_SLOT(uint8_t*, 9)      // pinned mailbox of read_header
+#define h_flag        T3_SLOT(uint32_t*, 10)    // mapped pinned failure counter of the synchronous decode entry
+#define d_flag_map    T3_SLOT(uint32_t*, 11)
+#define d_synd_lut    (&T3_SLOT(uint32_t*, 12)) // [4] per k index: syndrome LUT of the two-kernel decoder
+#define d_roots       (&T3_SLOT(uint32_t*, 16)) // [4] per k index: the Chien search (OLD:611-623) of every locator, tabulated
+#define d_synd_afrag  (&T3_SLOT(uint32_t*, 20)) // [4] per k index: A operand of the syndrome MFMA (t3_host.hpp build_mfma_syndrome)
+uint32_t synd_lut_bytes[4] = {0, 0, 0, 0};      // (a size, the same for every context)
 
 int k_index(int k) { return k == 24 ? 0 : k == 22 ? 1 : k == 20 ? 2 : k == 18 ? 3 : -1; }
 DevDiv to_dev(FastDiv f) { return DevDiv{f.mul, f.sh, f.d}; }
@@ -95,7 +105,7 @@ int ensure_fx_tables(int k) {
 
 // dequantiser tables of the fused RGB output stage (old/include/io_image.hpp:79-84: the reference's double expressions, tabulated)
 int rgb_dequant_tables(const uint8_t** out) {
-    static uint8_t* d = nullptr;
+    uint8_t*& d = d_rgb_dq;
     if (!d) {
         uint8_t t[328]; memset(t, 0, sizeof t);
         auto cl = [](long v) { return v < 0 ? 0 : (v > 255 ? 255 : v); };
@@ -346,7 +356,7 @@ int read_header(const void* d_in, uint64_t n_in, int mode, t3_cfg* seen, uint64_
     if (n_in < hw) return T3_E_HEADER;                                     // OLD:920
     // pinned mailbox: the 54/90 header bytes come back by a real asynchronous DMA (a pageable target costs a staging copy)
     std::lock_guard<std::recursive_mutex> lk(g_mail_mu);
-    static uint8_t* h = nullptr;
+    uint8_t*& h = h_mail;
     if (!h) HIPCHK(hipHostMalloc((void**)&h, 128, hipHostMallocDefault));
     HIPCHK(hipMemcpyAsync(h, d_in, hw * 9, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -356,11 +366,15 @@ int read_header(const void* d_in, uint64_t n_in, int mode, t3_cfg* seen, uint64_
 }  // namespace
 
 namespace t3 {
+void rgb_shutdown();
 void decode_shutdown() {
     std::lock_guard<std::mutex> lk(g_tab_mu);
     auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
-    fr(d_zpow); fr(d_crc_acc); fr(d_crc_afrag); fr(d_fxtab); fr(d_fma);
-    for (int i = 0; i < 4; ++i) { fr(d_synd_lut[i]); synd_lut_bytes[i] = 0; fr(d_roots[i]); fr(d_synd_afrag[i]); }
+    fr(d_zpow); fr(d_crc_acc); fr(d_crc_afrag); fr(d_fxtab); fr(d_fma); fr(d_rgb_dq);
+    if (h_mail) { (void)hipHostFree(h_mail); h_mail = nullptr; }
+    if (h_flag) { (void)hipHostFree(h_flag); h_flag = nullptr; d_flag_map = nullptr; }
+    rgb_shutdown();
+    for (int i = 0; i < 4; ++i) { fr(d_synd_lut[i]); fr(d_roots[i]); fr(d_synd_afrag[i]); }
     fr(d_synd_T); fr(d_synd_T16); fr(d_fx2_small);
 }
 int decode_init(const RsTables*) {
@@ -428,21 +442,10 @@ int t3hip_decode_frame_async(const void* d_in, uint64_t n_in, const t3_cfg* cfg,
     t3_layout L; int rc = plan(n_raw, *cfg, L); if (rc) return rc;
     const uint32_t hs = (uint32_t)header_encode(*cfg, n_raw, hdr);
     if (9 * n_in < hs) return T3_E_HEADER;
-    // the expected header symbols live on the device, one small buffer per distinct header ever asked for (a stream has one)
-    const uint8_t* d_exp = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_tab_mu);
-        static std::map<std::vector<uint8_t>, uint8_t*> known;
-        std::vector<uint8_t> key(hdr, hdr + 96);
-        auto it = known.find(key);
-        if (it == known.end()) {
-            if (known.size() >= 256) return T3_E_ARG;                           // not a stream any more: use the synchronous entry
-            uint8_t* d = nullptr; HIPCHK(hipMalloc((void**)&d, 96)); HIPCHK(hipMemcpy(d, hdr, 96, hipMemcpyHostToDevice));
-            it = known.emplace(std::move(key), d).first;
-        }
-        d_exp = it->second;
-    }
-    hipLaunchKernelGGL(hdr_compare_kernel, dim3(1), dim3(128), 0, s, (const uint8_t*)d_in, d_exp, hs, d_verdict);   // also zeroes the block counter
+    // the expected header symbols travel as a kernel argument (96 bytes): nothing to allocate, no limit on how many different
+    // headers a long-lived process may see
+    HdrExpect ex; memcpy(ex.b, hdr, 96);
+    hipLaunchKernelGGL(hdr_compare_kernel, dim3(1), dim3(128), 0, s, (const uint8_t*)d_in, ex, hs, d_verdict);   // also zeroes the block counter
     HIPCHK(hipGetLastError());
     const ScrCycle sc = scrambler_cycle(cfg->seed_a, cfg->seed_b, cfg->seed_s0);
     return decode_body(d_in, n_in, *cfg, n_raw, sc.next, d_out, cap, n_out, to_pixels, d_verdict + 1, s);
@@ -467,7 +470,6 @@ int t3hip_decode_profile_dev(const void* d_in, uint64_t n_in, t3_cfg* seen, void
     // failure counter in mapped pinned host memory: written only by lanes that give up on a block, read after the sync
     // without a copy (the previous synchronous call has drained, so the host may clear it directly)
     std::lock_guard<std::recursive_mutex> lk(g_mail_mu);
-    static uint32_t* h_flag = nullptr; static uint32_t* d_flag_map = nullptr;
     if (!h_flag) {
         HIPCHK(hipHostMalloc((void**)&h_flag, 64, hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void**)&d_flag_map, h_flag, 0));

@@ -12,6 +12,7 @@
 namespace t3 {
 int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr); std::recursive_mutex& api_host_mutex();
 int api_fail_hip(hipError_t e, const char* what);
+void*& api_slot(int id);
 int api_encode_rgb_fused(const void* d_rgb, uint64_t n_px, const t3_cfg* cfg, void* d_out, uint64_t cap, uint64_t* n_out, hipStream_t s);
 }  // namespace t3
 using namespace t3;
@@ -19,7 +20,7 @@ using namespace t3;
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return api_fail_hip(e_, #x); } while (0)
 
 namespace {
-QuantTables* d_qt = nullptr;
+#define d_qt (*(QuantTables**)&api_slot(32))     // per-context slot (t3_api.cpp)
 std::mutex g_qt_mu;
 int tables(const QuantTables** out) {
     std::lock_guard<std::mutex> lk(g_qt_mu);
@@ -36,6 +37,8 @@ int tables(const QuantTables** out) {
 }
 unsigned blocks_for(uint64_t items) { return (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, (items + 255) / 256), 1u << 30); }
 }  // namespace
+
+namespace t3 { void rgb_shutdown() { std::lock_guard<std::mutex> lk(g_qt_mu); if (d_qt) { (void)hipFree(d_qt); d_qt = nullptr; } } }
 
 extern "C" {
 

@@ -155,4 +155,14 @@ int t3hip_mod27_bytes(const uint8_t* in, uint64_t n, uint8_t* out) {
     return fetch(out, dout, n);
 }
 
+// measurement aid (profiles/copy_ceiling.py): a plain streaming kernel over the same byte volumes as a codec launch
+int t3hip_diag_stream_copy_dev(const void* d_src, uint64_t n_read, void* d_dst, uint64_t n_write, int blocks_per_cu, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (!d_src || !d_dst || (((uintptr_t)d_src | (uintptr_t)d_dst) & 15u)) return T3_E_ARG;
+    const int nt = blocks_per_cu < 0; if (nt) blocks_per_cu = -blocks_per_cu;                 // negative: non-temporal loads and stores
+    const unsigned grid = 256u * (unsigned)(blocks_per_cu > 0 ? blocks_per_cu : 8);
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_src, n_read / 16, (uint4*)d_dst, n_write / 16, nt);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+
 }  // extern "C"

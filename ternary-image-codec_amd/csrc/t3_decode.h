@@ -129,6 +129,7 @@ struct EmitStArgs {
     DevDiv div_A, div_w;
     uint32_t sym_off, o_off, lds_bytes;
 };
+struct HdrExpect { uint8_t b[96]; };          // the header symbols a configuration encodes to, passed by value
 struct DebeaconArgs { const uint8_t* framed; uint64_t framed_bytes; uint8_t* body; uint64_t body_syms; uint32_t period, slot; };   // framed_bytes: readable bytes from `framed`
 
 int decode_init(const RsTables* d_tab);
@@ -144,7 +145,7 @@ __global__ void debeacon_kernel(const DebeaconArgs a);
 __global__ void dec_emit_kernel(const EmitArgs a);
 __global__ void rs_decode_blocks_kernel(uint8_t* code, uint64_t n_blocks, int k, int fixed, const RsTables* tab, uint8_t* data, uint8_t* ok);
 __global__ void inject_errors_kernel(uint8_t* syms, uint64_t n_blocks, uint32_t seed, int max_err);
-__global__ void hdr_compare_kernel(const uint8_t* in, const uint8_t* expect, uint32_t n, uint32_t* mismatch);
+__global__ void hdr_compare_kernel(const uint8_t* in, HdrExpect expect, uint32_t n, uint32_t* mismatch);
 __global__ void crc_chunks_kernel(const CrcArgs a);
 __global__ void crc_mfma_kernel(const CrcMArgs a);
 __global__ void frame_record_kernel(const CrcArgs a, const uint8_t* words, uint64_t n_words, uint64_t frame_idx, uint32_t profile, uint32_t mode, void* rec);

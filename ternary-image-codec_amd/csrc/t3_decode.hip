@@ -217,8 +217,11 @@ __global__ __launch_bounds__(256) void crc_chunks_kernel(const CrcArgs a) {
 
 // header symbols of the frame against the ones the previous frame parsed to (speculative decode, t3_api_decode.cpp)
 // One workgroup; writes both verdict words: [0] = header differs, [1] = 0 (the body kernels count uncorrectable blocks into it)
-__global__ void hdr_compare_kernel(const uint8_t* in, const uint8_t* expect, uint32_t n, uint32_t* verdict) {
-    const int diff = __syncthreads_or(threadIdx.x < n && in[threadIdx.x] != expect[threadIdx.x]);
+__global__ void hdr_compare_kernel(const uint8_t* in, const HdrExpect expect, uint32_t n, uint32_t* verdict) {
+    __shared__ uint8_t ex[96];
+    if (threadIdx.x < 96) ex[threadIdx.x] = expect.b[threadIdx.x < 96 ? threadIdx.x : 0];     // (kernel arguments are not indexed dynamically: staged)
+    __syncthreads();
+    const int diff = __syncthreads_or(threadIdx.x < n && in[threadIdx.x] != ex[threadIdx.x]);
     if (threadIdx.x == 0) { verdict[0] = diff ? 1u : 0u; verdict[1] = 0u; }
 }
 

@@ -9,5 +9,6 @@ __global__ void subword_build_kernel(const uint8_t* trits, uint64_t n_trits, int
 __global__ void base243_pack_kernel(const uint8_t* trits, uint64_t n_trits, uint8_t* out);
 __global__ void base243_unpack_kernel(const uint8_t* in, uint64_t n_bytes, uint64_t total, uint8_t* trits);
 __global__ void mod27_bytes_kernel(const uint8_t* in, uint64_t n, uint8_t* out);
+__global__ void stream_copy_kernel(const uint4* src, uint64_t n_read16, uint4* dst, uint64_t n_write16, int nt);
 #endif
 }  // namespace t3

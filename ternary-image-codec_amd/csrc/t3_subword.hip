@@ -188,4 +188,29 @@ __global__ __launch_bounds__(256) void mod27_bytes_kernel(const uint8_t* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// measurement aid: the part's streaming ceiling for a kernel that reads n_read bytes and writes n_write bytes (16 bytes per lane,
+// four loads in flight per lane, persistent grid-stride) -- what profiles/copy_ceiling.py quotes beside the codec kernels
+// ---------------------------------------------------------------------------------------------------------
+template <bool NT>
+__device__ __forceinline__ void stream_copy_body(const uint4* __restrict__ src, uint64_t n_read16, uint4* __restrict__ dst, uint64_t n_write16) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n = n_read16 > n_write16 ? n_read16 : n_write16;
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    for (uint64_t i = i0; i < n; i += 4 * stride) {
+        v4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint64_t j = i + k * stride; v[k] = j < n_read16 ? (NT ? __builtin_nontemporal_load((const v4*)src + j) : ((const v4*)src)[j]) : v4{0, 0, 0, 0}; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t j = i + k * stride;
+            if (j < n_write16) { if (NT) __builtin_nontemporal_store(v[k], (v4*)dst + j); else ((v4*)dst)[j] = v[k]; }
+            else if (j < n_read16 && (v[k].x ^ v[k].y) == 0x9E3779B9u) ((v4*)dst)[0] = v[k];     // reads beyond the write volume stay live
+        }
+    }
+}
+__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4* __restrict__ src, uint64_t n_read16, uint4* __restrict__ dst, uint64_t n_write16, int nt) {
+    if (nt) stream_copy_body<true>(src, n_read16, dst, n_write16); else stream_copy_body<false>(src, n_read16, dst, n_write16);
+}
+
 }  // namespace t3

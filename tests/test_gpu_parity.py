@@ -673,6 +673,48 @@ def test_host_api_two_threads(gpu, orc):
 
 
 @pytest.mark.gpu
+def test_two_contexts_two_threads(t3, orc, gpu):
+    """One handle per GPU (t3hip_create / t3hip_use): two contexts (both on device 0 here: the box has one card) driven by two
+    threads at the same time, each encoding and decoding its own frames on its own stream, tables and scratch; the default
+    context keeps working beside them and after they are destroyed.  t3hip_init for another device while the default exists
+    is refused rather than silently rebinding."""
+    import threading
+    import torch
+    res = {}
+    def work(tag, n, seed, kw):
+        ctx = None
+        try:
+            ctx = t3.Context(0); ctx.use()
+            assert ctx.device() == 0 and t3.is_ready()
+            cfg, ocfg = both(gpu, kw, mode=1)
+            for rep in range(5):
+                px = orc.lcg_pixels(n + 13 * rep, seed + rep)
+                ok, enc = gpu.encode_frame(px, cfg)
+                rc, want = orc.encode_frame(px, ocfg, cap=len(px) + 64)
+                assert ok and rc == 0 and np.array_equal(enc, want), (tag, rep, "encode")
+                bad = orc.inject_errors(enc, 90, (len(enc) * 9 - 90) // 26, seed, 2)
+                okd, back = gpu.decode_frame(bad, gpu.DecoderContext(mode=1))
+                assert okd and np.array_equal(back[: len(px)], px), (tag, rep, "decode")
+            res[tag] = "ok"
+        except Exception as e:   # noqa: BLE001
+            res[tag] = repr(e)
+        finally:
+            if ctx is not None:
+                t3.Context.use_default(); ctx.destroy()
+    th = [threading.Thread(target=work, args=("a", 150_001, 5, dict(profile=2, uep=2))),
+          threading.Thread(target=work, args=("b", 70_003, 9, dict(profile=1, uep=1)))]
+    for t in th: t.start()
+    px = orc.lcg_pixels(40_000, 3); cfg, ocfg = both(gpu, dict(profile=2, uep=2), mode=0)       # the default context, meanwhile
+    ok, enc = gpu.encode_frame(px, cfg); rc, want = orc.encode_frame(px, ocfg, cap=len(px) + 64)
+    for t in th: t.join()
+    assert res == {"a": "ok", "b": "ok"}, res
+    assert ok and rc == 0 and np.array_equal(enc, want)
+    if torch.cuda.device_count() == 1:
+        assert t3.lib().t3hip_init(1) != 0                      # no such device / the default context stays where it is
+    ok, enc2 = gpu.encode_frame(px, cfg); assert ok and np.array_equal(enc2, want)
+
+
+@pytest.mark.gpu
 def test_shutdown_and_reinit(t3, orc, gpu):
     """t3hip_shutdown frees the device tables of both halves of the library; a new t3hip_init rebuilds them."""
     px = orc.lcg_pixels(5000, 1)
