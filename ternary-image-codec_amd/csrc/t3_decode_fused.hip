@@ -54,44 +54,6 @@ __device__ __forceinline__ void stage_tables(const DecFx2Args& a, const uint32_t
     if (tid < 64u) *(uint32_t*)(lds + a.af_off + 3072u + 4u * tid) = a.afrag[(3u * 64u + tid) * 4u];       // step 3: dword 0 of every lane
 }
 
-// E1 for the 64 blocks two sets leave with a wave (lower half-wave: set A, upper: set B): single errors fixed in place, the other
-// flagged blocks appended to the queue at q_off (syndromes, 8 bytes; item numbers, 2 bytes, behind qcap entries); a block that
-// finds the queue full is corrected on the spot.
-template <int R>
-__device__ __forceinline__ void fx2_own_blocks(const DecFx2Args& a, const Synd& sA, const Synd& sB, const Blk& bA, const Blk& bB, const uint32_t item,
-                                               const uint32_t lane, const uint32_t cnt_addr, const uint32_t q_off, const uint32_t qcap) {
-    const uint32_t h = lane >> 5;
-    Synd own; own.lo = h ? sB.lo : sA.lo; own.hi = h ? sB.hi : sA.hi;
-    const bool valid = h ? bB.valid : bA.valid;
-    const uint32_t yb = h ? bB.yb : bA.yb;
-    bool flagged = valid && (own.lo | own.hi) != 0u;                                // OLD:562: all-zero syndromes -> nothing to do
-    if (flagged) flagged = fx2_single<R>(own, yb, a.fma_off) == 0u;
-    const uint64_t bal = __builtin_amdgcn_ballot_w64(flagged);
-    if (bal != 0ull) {                                                              // wave-aggregated append: one LDS atomic per wave
-        const uint32_t cnt = (uint32_t)__popcll(bal), first = (uint32_t)__builtin_ctzll(bal);
-        uint32_t base = 0;
-        if (lane == first) base = __hip_atomic_fetch_add((uint32_t*)__builtin_assume_aligned(lds + cnt_addr, 4), cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        base = __builtin_amdgcn_readlane(base, (int)first);
-        if (flagged) {
-            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            if (__builtin_expect(slot < qcap, 1)) {
-                *T3_LP(u32x2, q_off + 8u * slot) = u32x2{own.lo, own.hi};              // the r syndromes ...
-                *T3_LP(uint16_t, q_off + 8u * qcap + 2u * slot) = (uint16_t)item;      // ... and the block's item number (< 512)
-            } else if (!fx2_fix_block<R>(own.lo, own.hi, yb, a.roots, a.fma_off)) atomicAdd(a.fail, 1u);   // queue full (cold)
-        }
-    }
-}
-
-// BM for queue entry e: the block's symbols are at y_off + band + 9 K (block within the tile)
-template <int R>
-__device__ __forceinline__ void fx2_queue_entry(const DecFx2Args& a, const uint32_t e, const uint32_t q_off, const uint32_t qcap, const uint32_t y_off) {
-    constexpr uint32_t K = 26 - R;
-    const u32x2 sy = *T3_LP(const u32x2, q_off + 8u * e);
-    const uint32_t item = *T3_LP(const uint16_t, q_off + 8u * qcap + 2u * e);
-    const uint32_t bi = min(__umulhi(item, a.div_nb.mul) >> a.div_nb.sh, 8u), m = item - bi * a.nb;
-    if (!fx2_fix_block<R>(sy.x, sy.y, y_off + bi + 9u * K * m, a.roots, a.fma_off)) atomicAdd(a.fail, 1u);
-}
-
 // D5 (pixels) for lane slot j of a tile: four triples = 52 symbols at y_off + 52 j -> 12 pixels = 72 bytes; RGB: the inverse
 // io_image.hpp bridge fused in (dequantize_ycbcr :79-84 by table, ycbcr_to_rgb :57-66 with every float step rounded on its own,
 // std::lround + clamp to 0..255 = min(trunc(x + 0.5) from zero up, 255)) -> 36 bytes
@@ -202,7 +164,7 @@ __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_px_kern
                 const Synd sA = fx2_set<R, TCOP, TBASE, MT>(bA, LA, lane, a.af_off, a.cyc24, a.pre0, a.pre1);
                 Synd sB; sB.lo = 0; sB.hi = 0;
                 if (wave * 128u + pass * 64u + 32u < n_items) sB = fx2_set<R, TCOP, TBASE, MT>(bB, LB, lane, a.af_off, a.cyc24, a.pre0, a.pre1);
-                fx2_own_blocks<R>(a, sA, sB, bA, bB, wave * 128u + pass * 64u + lane, lane, kFx2Cnt + 4u * buf, q_off, QCAP);
+                fx2_own_blocks<R>(a.roots, a.fma_off, a.fail, sA, sB, bA, bB, (h ? geo[pass][1] : geo[pass][0]) & 0xFFFFu, lane, kFx2Cnt + 4u * buf, q_off, QCAP);
             }
             T3D_STAMP(0);
             barrier_lds2();
@@ -220,7 +182,7 @@ __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_px_kern
                 const uint32_t tile = blockIdx.x + (k - 1u) * grid, buf = (k - 1u) & 1u;
                 const uint32_t y_off = a.y_off + buf * a.y_stride, q_off = a.q_off + buf * a.q_stride;
                 const uint32_t Q = min(*(const uint32_t*)(lds + kFx2Cnt + 4u * buf), QCAP);
-                for (uint32_t e0 = cw * 64u; e0 < Q; e0 += 256u) { const uint32_t e = e0 + lane; if (e < Q) fx2_queue_entry<R>(a, e, q_off, QCAP, y_off); }
+                for (uint32_t e0 = cw * 64u; e0 < Q; e0 += 256u) { const uint32_t e = e0 + lane; if (e < Q) fx2_queue_entry<R>(a.roots, a.fma_off, a.fail, e, q_off, QCAP, y_off); }
                 T3D_STAMP(2);
                 // rendezvous of the four consumer waves: every patch is in LDS before any wave converts symbols
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -290,11 +252,11 @@ __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_kernel(
                 PB = load16(src_of(fx2_block<R>(gB, nt * a.nb, mod3u(nt * a.nb), a.y_off)));
             }
         }
-        fx2_own_blocks<R>(a, sA, sB, bA, bB, wave * 64u + lane, lane, kFx2Cnt + 4u * par, a.q_off, 512u);
+        fx2_own_blocks<R>(a.roots, a.fma_off, a.fail, sA, sB, bA, bB, (h ? gB0 : gA0) & 0xFFFFu, lane, kFx2Cnt + 4u * par, a.q_off, 512u);
         barrier_lds2();
         {
             const uint32_t Q = *(const uint32_t*)(lds + kFx2Cnt + 4u * par);
-            for (uint32_t e0 = wave * 64u; e0 < Q; e0 += nthr) { const uint32_t e = e0 + lane; if (e < Q) fx2_queue_entry<R>(a, e, a.q_off, 512u, a.y_off); }
+            for (uint32_t e0 = wave * 64u; e0 < Q; e0 += nthr) { const uint32_t e = e0 + lane; if (e < Q) fx2_queue_entry<R>(a.roots, a.fma_off, a.fail, e, a.q_off, 512u, a.y_off); }
             if (tid == 0) *(uint32_t*)(lds + kFx2Cnt + 4u * (par ^ 1u)) = 0;        // the next tile's counter (nobody touches it in this phase)
         }
         barrier_lds2();

@@ -19,7 +19,7 @@ typedef int v4i_ __attribute__((ext_vector_type(4)));
 typedef int v16i_ __attribute__((ext_vector_type(16)));
 struct __attribute__((packed, aligned(2))) U128a2_ { uint32_t v[4]; };
 
-constexpr uint32_t SM = kFx2Small;     // small byte tables (27 entries: at most 7 dwords = 7 banks, conflict-free)
+// SMB + kFx2Small: LDS offset of the small byte tables (27 entries: at most 7 dwords = 7 banks, conflict-free)
 __device__ __forceinline__ uint32_t mod26(uint32_t u) { return min(u, u + 26u); }   // u = a - b as uint32, a, b < 26
 
 // What a set leaves with the two lanes of a block: the r syndromes, h = 0 half (S_0 .. S_{r/2-1}, one byte each) and h = 1 half
@@ -58,7 +58,7 @@ __device__ __forceinline__ Blk fx2_block(const Geo g, const uint32_t tb, const u
 // the caller (prefetched ahead).  The three mod-3 fold tables M_t[x] = 3^t ((x - 81) mod 3) are 160 B each.
 // TCOP bank copies of the T table at LDS offset TBASE (32: conflict-free; 16: lanes n and n + 16 share a copy, two-way conflicts,
 // half the space); MT: LDS offset of the fold tables (a compile-time constant, so that it rides in the instruction's offset field).
-template <int R, uint32_t TCOP, uint32_t TBASE, uint32_t MT>
+template <int R, uint32_t TCOP, uint32_t TBASE, uint32_t MT, uint32_t SMB = 0>
 __device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], const uint32_t lane, const uint32_t af_off,
                                         const uint32_t cyc24, const uint32_t pre0, const uint32_t pre1) {
     constexpr uint32_t TSTATE = 27u * 4u * TCOP, mt = MT;
@@ -94,7 +94,7 @@ __device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], c
     const uint32_t vb1 = fst ? pre1 * TSTATE + tb0 : vb[1];
     // data symbols -> stream order (byte 2 of a T entry = the descrambled symbol): h = 0 holds positions 0..12, h = 1 13..25, of
     // which K..25 are parity; lanes without a block write into a dummy area instead of being masked off store by store
-    const uint32_t ya = b.valid ? b.yb + 117u * h : kFx2Dummy;                     // 9 * 13
+    const uint32_t ya = b.valid ? b.yb + 117u * h : SMB + kFx2Dummy;               // 9 * 13
     v16i_ acc = {81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81};     // bias: trit sums in [-78, 78] -> [3, 159]
     // The table reads of K-step st + 1 are issued before the MFMA of step st (one step of entries in flight beside the one being
     // consumed: the LDS latency of a step hides under the previous step's MFMA), no further (80-VGPR budget).
@@ -144,8 +144,9 @@ __device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], c
 }
 
 // Single-error closed form for the lane's own block.  Returns 0: not a single error (-> queue), 1: fixed (or only parity hit).
-template <int R>
+template <int R, uint32_t SMB = 0>
 __device__ __forceinline__ uint32_t fx2_single(const Synd& sy, const uint32_t yb, const uint32_t FMA) {
+    constexpr uint32_t SM = SMB + kFx2Small;
     constexpr uint32_t K = 26 - R, H = R / 2;
     uint32_t lg[R]; bool ok = true;
 #pragma unroll
@@ -170,8 +171,9 @@ __device__ __forceinline__ uint32_t fx2_single(const Synd& sy, const uint32_t yb
 // 2: outside the short routine's conditions (the caller runs fx_correct on this lane).
 // Table index of a + x y = FMA + 729 x + 27 y + a; multiplication commutes, so the operand that is known early carries the
 // factor 729 (and the table base) and the other one the factor 27: one v_add3 per multiply-accumulate.
-template <int R>
+template <int R, uint32_t SMB = 0>
 __device__ __forceinline__ uint32_t fx2_correct(const uint32_t* S, Fix& fx, const uint32_t* __restrict__ root_tbl, const uint32_t FMA) {
+    constexpr uint32_t SM = SMB + kFx2Small;
     constexpr int T = R / 2;
     auto tab = [](uint32_t idx) -> uint32_t { return l8(idx); };
     uint32_t Sx[R];                                                                // FMA + 729 S_j
@@ -246,8 +248,9 @@ __device__ __forceinline__ uint32_t fx2_correct(const uint32_t* S, Fix& fx, cons
 
 // The full-length routine (fx_correct of t3_decode_fx.h: sigma on R + 2 coefficients, every Omega coefficient) with all of its
 // arithmetic on the multiply-accumulate table and the small byte tables, for the kernels that do not stage FxTables.
-template <int R>
+template <int R, uint32_t SMB = 0>
 __device__ __forceinline__ bool fx2_correct_full(const uint32_t* S, Fix& fx, const uint32_t* __restrict__ root_tbl, const uint32_t FMA) {
+    constexpr uint32_t SM = SMB + kFx2Small;
     auto fma = [FMA](uint32_t acc, uint32_t x, uint32_t y) -> uint32_t { return l8(FMA + (x * 27u + y) * 27u + acc); };   // acc + x y
     constexpr int T = R / 2, NP = R + 2;
     uint32_t sg[NP], bx[NP];
@@ -309,20 +312,57 @@ __device__ __forceinline__ bool fx2_correct_full(const uint32_t* S, Fix& fx, con
 }
 
 // One queued block: syndromes -> corrections patched into the symbol buffer at yb; returns false for an uncorrectable block.
-template <int R>
+template <int R, uint32_t SMB = 0>
 __device__ __forceinline__ bool fx2_fix_block(const uint32_t lo, const uint32_t hi, const uint32_t yb, const uint32_t* __restrict__ root_tbl, const uint32_t FMA) {
     constexpr uint32_t K = 26 - R, H = R / 2;
     uint32_t S[R];
 #pragma unroll
     for (uint32_t j = 0; j < (uint32_t)R; ++j) S[j] = ((j < H ? lo : hi) >> (8u * (j % H))) & 0xFFu;
     Fix fx; fx.np = 0;
-    uint32_t rc = fx2_correct<R>(S, fx, root_tbl, FMA);
-    if (rc == 2u) rc = fx2_correct_full<R>(S, fx, root_tbl, FMA) ? 0u : 1u;      // longer register than t: the full-length routine decides
+    uint32_t rc = fx2_correct<R, SMB>(S, fx, root_tbl, FMA);
+    if (rc == 2u) rc = fx2_correct_full<R, SMB>(S, fx, root_tbl, FMA) ? 0u : 1u;      // longer register than t: the full-length routine decides
     if (rc != 0u) return false;
 #pragma unroll
     for (int q = 0; q < R / 2; ++q)
         if ((uint32_t)q < fx.np && fx.pos[q] < K) { const uint32_t ad = yb + 9u * fx.pos[q]; *T3_LP(uint8_t, ad) = (uint8_t)l8(FMA + (54u + fx.mag[q]) * 27u + l8(ad)); }   // y - m = y + 2 m
     return true;
+}
+
+// E1 for the 64 blocks two sets leave with a wave (lower half-wave: set A, upper: set B): single errors fixed in place, the other
+// flagged blocks appended to the queue at q_off (syndromes, 8 bytes; block tags, 2 bytes, behind qcap entries); a block that
+// finds the queue full is corrected on the spot.
+template <int R, uint32_t SMB = 0>
+__device__ __forceinline__ void fx2_own_blocks(const uint32_t* __restrict__ roots, const uint32_t fma_off, uint32_t* fail, const Synd& sA, const Synd& sB, const Blk& bA, const Blk& bB, const uint32_t tag,
+                                               const uint32_t lane, const uint32_t cnt_addr, const uint32_t q_off, const uint32_t qcap) {
+    const uint32_t h = lane >> 5;
+    Synd own; own.lo = h ? sB.lo : sA.lo; own.hi = h ? sB.hi : sA.hi;
+    const bool valid = h ? bB.valid : bA.valid;
+    const uint32_t yb = h ? bB.yb : bA.yb;
+    bool flagged = valid && (own.lo | own.hi) != 0u;                                // OLD:562: all-zero syndromes -> nothing to do
+    if (flagged) flagged = fx2_single<R, SMB>(own, yb, fma_off) == 0u;
+    const uint64_t bal = __builtin_amdgcn_ballot_w64(flagged);
+    if (bal != 0ull) {                                                              // wave-aggregated append: one LDS atomic per wave
+        const uint32_t cnt = (uint32_t)__popcll(bal), first = (uint32_t)__builtin_ctzll(bal);
+        uint32_t base = 0;
+        if (lane == first) base = __hip_atomic_fetch_add((uint32_t*)__builtin_assume_aligned(lds + cnt_addr, 4), cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = __builtin_amdgcn_readlane(base, (int)first);
+        if (flagged) {
+            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (__builtin_expect(slot < qcap, 1)) {
+                *T3_LP(u32x2, q_off + 8u * slot) = u32x2{own.lo, own.hi};              // the r syndromes ...
+                *T3_LP(uint16_t, q_off + 8u * qcap + 2u * slot) = (uint16_t)tag;       // ... and the block: block within the tile | band << 12
+            } else if (!fx2_fix_block<R, SMB>(own.lo, own.hi, yb, roots, fma_off)) atomicAdd(fail, 1u);   // queue full (cold)
+        }
+    }
+}
+
+// BM for queue entry e: the block's symbols are at y_off + band + 9 K (block within the tile)
+template <int R, uint32_t SMB = 0>
+__device__ __forceinline__ void fx2_queue_entry(const uint32_t* __restrict__ roots, const uint32_t fma_off, uint32_t* fail, const uint32_t e, const uint32_t q_off, const uint32_t qcap, const uint32_t y_off) {
+    constexpr uint32_t K = 26 - R;
+    const u32x2 sy = *T3_LP(const u32x2, q_off + 8u * e);
+    const uint32_t tag = *T3_LP(const uint16_t, q_off + 8u * qcap + 2u * e);
+    if (!fx2_fix_block<R, SMB>(sy.x, sy.y, y_off + (tag >> 12) + 9u * K * (tag & 0xFFFu), roots, fma_off)) atomicAdd(fail, 1u);
 }
 
 }  // namespace

@@ -169,6 +169,25 @@ def test_bench_two_rank_rehearsal(gpu):
 
 
 @pytest.mark.gpu
+def test_bench_distributed_path_one_rank(gpu):
+    """bench.py's N > 1 code path with the real collectives on this box's one card: launched under torch.distributed.run with one
+    rank and T3_BENCH_FORCE_DIST=1 it initialises the process group (gloo + RCCL), creates the library's RCCL communicator from a
+    broadcast unique id, runs the warm-up exchange and the timed t3hip_index_allgather, and checks the assembled index."""
+    import socket
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(T3_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2", "--settle-ms", "5", "--frames-per-rank", "2",
+                        "--no-cpu-baseline", "--no-end-to-end", "--no-rgb"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 8 and line["value"] > 0
+
+
+@pytest.mark.gpu
 def test_comm_single_rank(gpu):
     """The library's RCCL entry points on real hardware (a communicator of one rank: unique id, ncclCommInitRank,
     ncclAllGather of frame records on a stream, destroy)."""
