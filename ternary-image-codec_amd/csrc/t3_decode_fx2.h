@@ -95,7 +95,9 @@ __device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], c
     // data symbols -> stream order (byte 2 of a T entry = the descrambled symbol): h = 0 holds positions 0..12, h = 1 13..25, of
     // which K..25 are parity; lanes without a block write into a dummy area instead of being masked off store by store
     const uint32_t ya = b.valid ? b.yb + 117u * h : SMB + kFx2Dummy;               // 9 * 13
-    v16i_ acc = {81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81, 81};     // bias: trit sums in [-78, 78] -> [3, 159]
+    // bias 64 (the largest inline constant: the first MFMA takes it as its C operand, no register initialisation): trit sums in
+    // [-78, 78] -> [-14, 142], and the fold tables are entered at index + 14
+    v16i_ acc = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64};
     // The table reads of K-step st + 1 are issued before the MFMA of step st (one step of entries in flight beside the one being
     // consumed: the LDS latency of a step hides under the previous step's MFMA), no further (80-VGPR budget).
     auto fetch = [&](const uint32_t st, v4i_& Bv) {
@@ -119,23 +121,22 @@ __device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], c
             }
         }
     };
-    v4i_ Bcur, Bnext;
-    fetch(0, Bcur);
+    v4i_ Bq[2];                                                                   // double buffer by step parity (no copies)
+    fetch(0, Bq[0]);
 #pragma unroll
     for (uint32_t st = 0; st < 4; ++st) {
-        if (st < 3u) fetch(st + 1u, Bnext);
+        if (st < 3u) fetch(st + 1u, Bq[(st + 1u) & 1u]);
         // the syndrome matrix lives in LDS (80-VGPR budget): three full steps, then step 3 of which only dword 0 (position 12) is used
         v4i_ Af = {0, 0, 0, 0};
         if (st < 3u) Af = *T3_LP(const v4i_, af_off + 16u * (64u * st + lane)); else Af[0] = *T3_LP(const int, af_off + 3072u + 4u * lane);
-        emit(st, Bcur);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af, Bcur, acc, 0, 0, 0);
-        Bcur = Bnext;
+        emit(st, Bq[st & 1u]);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af, Bq[st & 1u], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
     uint32_t Pown = 0;
 #pragma unroll
     for (uint32_t jj = 0; jj < H; ++jj) {                                          // mod-3 fold and 3^t weight by byte tables
-        const uint32_t s = l8(mt + (uint32_t)acc[3 * jj]) + l8(mt + 160u + (uint32_t)acc[3 * jj + 1]) + l8(mt + 320u + (uint32_t)acc[3 * jj + 2]);
+        const uint32_t s = l8(mt + 14u + (uint32_t)acc[3 * jj]) + l8(mt + 174u + (uint32_t)acc[3 * jj + 1]) + l8(mt + 334u + (uint32_t)acc[3 * jj + 2]);
         Pown |= s << (8u * jj);
     }
     const auto sw = __builtin_amdgcn_permlane32_swap(Pown, Pown, false, false);    // [0]: every lane sees the h = 0 half, [1]: the h = 1 half

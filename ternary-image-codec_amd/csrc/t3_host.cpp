@@ -266,7 +266,7 @@ void build_fx2_small(uint8_t out[kFx2SmallBytes]) {
     for (int i = 0; i < 26; ++i) out[kFx2EX + i] = F.t.exp[i];
 }
 void build_fx2_mod(uint8_t out[kFx2ModBytes]) {
-    for (int t = 0; t < 3; ++t) for (int x = 0; x < 160; ++x) out[160 * t + x] = (uint8_t)((((x - 81) % 3 + 3) % 3) * (t == 0 ? 1 : t == 1 ? 3 : 9));
+    for (int t = 0; t < 3; ++t) for (int x = 0; x < 160; ++x) out[160 * t + x] = (uint8_t)((((x - 78) % 3 + 3) % 3) * (t == 0 ? 1 : t == 1 ? 3 : 9));   // index = trit sum + 64 + 14
 }
 
 // ---- scrambler ----------------------------------------------------------------------------------------

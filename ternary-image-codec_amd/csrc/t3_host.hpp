@@ -88,7 +88,7 @@ constexpr int kFx2LG = 0, kFx2EX = 32, kFx2INV = 64, kFx2NEG = 96, kFx2NINV = 12
 void build_mfma_syndrome(int k, std::vector<uint32_t>& afrag);          // 4 * 64 * 4 dwords
 void build_syndrome_T(std::vector<uint32_t>& img, int copies = 32);      // 3 * 27 * copies dwords
 void build_fx2_small(uint8_t out[kFx2SmallBytes]);
-constexpr int kFx2ModBytes = 3 * 160;                                   // M_t[x] = 3^t ((x - 81) mod 3), x < 160: fold of a biased trit sum
+constexpr int kFx2ModBytes = 3 * 160;                                   // M_t[i] = 3^t ((i - 78) mod 3), i = trit sum + 64 (MFMA bias) + 14 < 160: fold of a biased trit sum
 void build_fx2_mod(uint8_t out[kFx2ModBytes]);
 
 // ---- scrambler (OLD:77-94) ------------------------------------------------------------------------
