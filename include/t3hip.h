@@ -296,6 +296,17 @@ int t3hip_base243_pack_dev(const uint8_t* d_trits, uint64_t n_trits, uint8_t* d_
 /* total = the trit count of the 4-byte header (the host entry point reads it itself) */
 int t3hip_base243_unpack_dev(const uint8_t* d_in, uint64_t n_bytes, uint64_t total, uint8_t* d_trits, void* stream);
 int t3hip_mod27_bytes_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, void* stream);
+/* Centring blits of row f3, old/include/io_image.hpp:125-140 (blit_center_rgb) and :215-235 (extract_center_q); parity unpinned
+ * like the rest of io_image.hpp (restated from the text, checked against the oracle's restatement).
+ *   blit    : sw x sh RGB8 image into the middle of a zeroed cw x ch canvas, x0 = max(0,(cw-sw)/2), y0 = max(0,(ch-sh)/2); source
+ *             rows that fall below the canvas are dropped.  sw > cw is T3_E_ARG (the reference overruns the canvas row there).
+ *   extract : the sw x sh window in the middle of a fw x fh frame of 6-byte pixels; window rows below the frame come out zero.
+ *             sw > fw is T3_E_ARG (the reference reads on into the next frame row).
+ * Device pointers: destination 4-byte aligned. */
+int t3hip_blit_center_rgb(const uint8_t* src, int sw, int sh, uint8_t* dst, int cw, int ch);
+int t3hip_extract_center_q(const void* full_px6, int fw, int fh, void* sub_px6, int sw, int sh);
+int t3hip_blit_center_rgb_dev(const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int cw, int ch, void* stream);
+int t3hip_extract_center_q_dev(const void* d_full_px6, int fw, int fh, void* d_sub_px6, int sw, int sh, void* stream);
 
 /* ---- SURVEY 8 row f1 (first version, own kernels): RGB8 <-> quantised YCbCr bridge ------------
  * rgb_to_quant_stream / quant_stream_to_rgb, old/include/io_image.hpp:47-90,156-195: float BT.601-style conversion with

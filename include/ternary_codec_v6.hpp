@@ -260,6 +260,20 @@ inline void quant_stream_to_rgb(const std::vector<PixelYCbCrQuant>& q, int w, in
     t3::ok(t3hip_quant_to_rgb(q.data(), m, out.data.data()));
 }
 
+// centring blits, io_image.hpp:125-140 and :215-235 (a source wider than the canvas / a window wider than the frame, where the
+// reference runs over the row, leaves the zeroed canvas / an all-zero window)
+inline void blit_center_rgb(const ImageU8& src, int canvasW, int canvasH, ImageU8& dst) {
+    dst.w = canvasW; dst.h = canvasH; dst.c = 3;
+    dst.data.assign((size_t)(canvasW > 0 ? canvasW : 0) * (size_t)(canvasH > 0 ? canvasH : 0) * 3, 0);
+    if (dst.data.empty() || src.w <= 0 || src.h <= 0 || !t3::ensure_device()) return;
+    t3::ok(t3hip_blit_center_rgb(src.data.data(), src.w, src.h, dst.data.data(), canvasW, canvasH));
+}
+inline void extract_center_q(const std::vector<PixelYCbCrQuant>& q_full, int fullW, int fullH, int subW, int subH, std::vector<PixelYCbCrQuant>& q_sub) {
+    q_sub.assign((size_t)(subW > 0 ? subW : 0) * (size_t)(subH > 0 ? subH : 0), PixelYCbCrQuant{});
+    if (q_sub.empty() || fullW <= 0 || fullH <= 0 || q_full.size() < (size_t)fullW * (size_t)fullH || !t3::ensure_device()) return;
+    t3::ok(t3hip_extract_center_q(q_full.data(), fullW, fullH, q_sub.data(), subW, subH));
+}
+
 // ---- subword trit streams (OLD:834-859) and wire packings (include/ternary_packing.hpp, namespace tpack) --------------
 inline void extract_subword_stream_from_words(const std::vector<Word27>& words, int N, std::vector<UTrit>& out) {
     out.clear();

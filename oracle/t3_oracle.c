@@ -694,3 +694,26 @@ void t3o_inject_errors(void* words9, uint64_t first_sym, uint64_t n_blocks, uint
         }
     }
 }
+
+/* ---- centring blits (row f3), old/include/io_image.hpp:125-140 and :215-235 ----
+ * PARITY UNPINNED like the rest of io_image.hpp (the header does not compile in this image): restated from the text.
+ * blit: zeroed canvas, source rows copied at (x0, y0) = (max(0,(cw-sw)/2), max(0,(ch-sh)/2)), rows past the canvas dropped.
+ * Requires sw <= cw (the reference overruns the canvas row otherwise). */
+void t3o_blit_center_rgb(const uint8_t* src, int sw, int sh, uint8_t* dst, int cw, int ch) {
+    memset(dst, 0, (size_t)cw * (size_t)ch * 3);
+    const int x0 = (cw - sw) / 2 > 0 ? (cw - sw) / 2 : 0, y0 = (ch - sh) / 2 > 0 ? (ch - sh) / 2 : 0;
+    for (int y = 0; y < sh; ++y) {
+        if (y + y0 < 0 || y + y0 >= ch) continue;
+        memcpy(dst + (size_t)(y + y0) * cw * 3 + (size_t)x0 * 3, src + (size_t)y * sw * 3, (size_t)sw * 3);
+    }
+}
+/* extract: the sw x sh window at (x0, y0) of a fw x fh frame of 6-byte pixels; rows below the frame are zero pixels.  sw <= fw. */
+void t3o_extract_center_q(const void* full_px6, int fw, int fh, void* sub_px6, int sw, int sh) {
+    const uint8_t* f = (const uint8_t*)full_px6; uint8_t* o = (uint8_t*)sub_px6;
+    const int x0 = (fw - sw) / 2 > 0 ? (fw - sw) / 2 : 0, y0 = (fh - sh) / 2 > 0 ? (fh - sh) / 2 : 0;
+    for (int y = 0; y < sh; ++y) {
+        const int fy = y + y0;
+        if (fy < 0 || fy >= fh) { memset(o + (size_t)y * sw * 6, 0, (size_t)sw * 6); continue; }
+        memcpy(o + (size_t)y * sw * 6, f + ((size_t)fy * fw + (size_t)x0) * 6, (size_t)sw * 6);
+    }
+}

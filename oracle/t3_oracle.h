@@ -56,6 +56,9 @@ uint64_t t3o_extract_subword_stream(const void* words9, uint64_t n_words, int N,
 uint64_t t3o_build_words_from_subword_stream(const uint8_t* trits, uint64_t n, int N, uint8_t fill, void* words9);
 uint64_t t3o_ut_to_base243(const uint8_t* trits, uint64_t n, uint8_t* out);
 int64_t  t3o_base243_to_ut(const uint8_t* bytes, uint64_t n, uint8_t* trits_out);
+/* centring blits, old/include/io_image.hpp:125-140, 215-235 (parity unpinned, see the header note on io_image.hpp) */
+void t3o_blit_center_rgb(const uint8_t* src, int sw, int sh, uint8_t* dst, int cw, int ch);
+void t3o_extract_center_q(const void* full_px6, int fw, int fh, void* sub_px6, int sw, int sh);
 void     t3o_words_to_bytes(const void* words9, uint64_t n_words, uint8_t* out);
 uint64_t t3o_bytes_to_words(const uint8_t* bytes, uint64_t n, void* words9);
 

@@ -334,6 +334,33 @@ def base243_to_ut(data):  # TPACK:40-50 -> trits, or None where the reference re
     return out[: nt.value]
 
 
+def blit_center_rgb(src, sw, sh, cw, ch):  # io_image.hpp:125-140 -> uint8 canvas (ch, cw, 3)
+    a = _u8(src)
+    if len(a) != sw * sh * 3:
+        raise ValueError("blit_center_rgb: %d bytes for a %dx%d image" % (len(a), sw, sh))
+    out = np.zeros(cw * ch * 3, np.uint8)
+    _chk(lib().t3hip_blit_center_rgb(_vp(a), C.c_int(sw), C.c_int(sh), _vp(out), C.c_int(cw), C.c_int(ch)), "t3hip_blit_center_rgb")
+    return out.reshape(ch, cw, 3)
+
+
+def extract_center_q(full, fw, fh, sw, sh):  # io_image.hpp:215-235 -> pixel records (sh * sw)
+    f = np.ascontiguousarray(full)
+    raw = f.view(np.uint8).reshape(-1)
+    if len(raw) != fw * fh * 6:
+        raise ValueError("extract_center_q: %d bytes for a %dx%d frame" % (len(raw), fw, fh))
+    out = np.zeros(sw * sh * 6, np.uint8)
+    _chk(lib().t3hip_extract_center_q(_vp(raw), C.c_int(fw), C.c_int(fh), _vp(out), C.c_int(sw), C.c_int(sh)), "t3hip_extract_center_q")
+    return out.view(f.dtype) if f.dtype.itemsize == 6 else out
+
+
+def blit_center_rgb_dev(d_src, sw, sh, d_dst, cw, ch, stream=0):
+    _chk(lib().t3hip_blit_center_rgb_dev(C.c_void_p(d_src), C.c_int(sw), C.c_int(sh), C.c_void_p(d_dst), C.c_int(cw), C.c_int(ch), C.c_void_p(stream)), "t3hip_blit_center_rgb_dev")
+
+
+def extract_center_q_dev(d_full, fw, fh, d_sub, sw, sh, stream=0):
+    _chk(lib().t3hip_extract_center_q_dev(C.c_void_p(d_full), C.c_int(fw), C.c_int(fh), C.c_void_p(d_sub), C.c_int(sw), C.c_int(sh), C.c_void_p(stream)), "t3hip_extract_center_q_dev")
+
+
 def words_to_bytes(words):  # TPACK:53-58
     w = np.ascontiguousarray(words, np.uint8).reshape(-1)
     out = np.zeros(len(w), np.uint8)

@@ -84,6 +84,38 @@ int t3hip_mod27_bytes_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, void*
     HIPCHK(hipGetLastError()); return T3_OK;
 }
 
+
+// ---- centring blits (io_image.hpp:125-140, 215-235) ----
+// blit_center_rgb: the source image lands in the middle of a zeroed canvas, x0 = max(0, (cw - sw) / 2), y0 likewise; source rows
+// that fall below the canvas are dropped as the reference drops them.  A source wider than the canvas is refused: the reference
+// copies sw * 3 bytes into a cw * 3 byte row there (it runs over the following rows and, on the last one, off the buffer).
+int t3hip_blit_center_rgb_dev(const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int cw, int ch, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (sw < 0 || sh < 0 || cw < 0 || ch < 0 || sw > cw) return T3_E_ARG;
+    const uint64_t dst_bytes = (uint64_t)cw * (uint64_t)ch * 3u;
+    if (!dst_bytes) return T3_OK;
+    if (!d_dst || ((uintptr_t)d_dst & 3u) || ((uint64_t)sw * sh && !d_src)) return T3_E_ARG;
+    const uint32_t x0 = (uint32_t)((cw - sw) / 2), y0 = (uint32_t)(ch > sh ? (ch - sh) / 2 : 0);
+    const uint32_t rows = (uint32_t)(sh < ch - (int)y0 ? sh : ch - (int)y0);
+    hipLaunchKernelGGL(center_window_kernel, dim3(blocks_for((dst_bytes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_src, (uint64_t)sw * 3u, 0u, (uint64_t)0,
+                       d_dst, (uint64_t)cw * 3u, dst_bytes, y0, rows, (uint64_t)x0 * 3u, (uint64_t)sw * 3u);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+// extract_center_q: the sw x sh window in the middle of a fw x fh frame of 6-byte pixels; window rows below the frame come out
+// zero (the reference's resize()).  A window wider than the frame is refused (the reference reads on into the next frame row).
+int t3hip_extract_center_q_dev(const void* d_full_px6, int fw, int fh, void* d_sub_px6, int sw, int sh, void* stream) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    if (fw < 0 || fh < 0 || sw < 0 || sh < 0 || sw > fw) return T3_E_ARG;
+    const uint64_t dst_bytes = (uint64_t)sw * (uint64_t)sh * 6u;
+    if (!dst_bytes) return T3_OK;
+    if (!d_sub_px6 || ((uintptr_t)d_sub_px6 & 3u) || ((uint64_t)fw * fh && !d_full_px6)) return T3_E_ARG;
+    const uint32_t x0 = (uint32_t)((fw - sw) / 2), y0 = (uint32_t)(fh > sh ? (fh - sh) / 2 : 0);
+    const uint32_t rows = (uint32_t)(sh < fh - (int)y0 ? sh : fh - (int)y0);
+    hipLaunchKernelGGL(center_window_kernel, dim3(blocks_for((dst_bytes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_full_px6, (uint64_t)fw * 6u, y0,
+                       (uint64_t)x0 * 6u, (uint8_t*)d_sub_px6, (uint64_t)sw * 6u, dst_bytes, 0u, rows, (uint64_t)0, (uint64_t)sw * 6u);
+    HIPCHK(hipGetLastError()); return T3_OK;
+}
+
 // ---- host-buffer entry points (what the std::vector API of include/ternary_codec_v6.hpp binds) ----
 static int roundtrip(const void* in, uint64_t in_bytes, void** di, uint64_t out_bytes, void** dout) {
     int rc = api_scratch(0, in_bytes + 64, di); if (rc) return rc;
@@ -153,6 +185,29 @@ int t3hip_mod27_bytes(const uint8_t* in, uint64_t n, uint8_t* out) {
     void *di, *dout; int rc = roundtrip(in, n, &di, n, &dout); if (rc) return rc;
     rc = t3hip_mod27_bytes_dev((const uint8_t*)di, n, (uint8_t*)dout, api_stream()); if (rc) return rc;
     return fetch(out, dout, n);
+}
+
+int t3hip_blit_center_rgb(const uint8_t* src, int sw, int sh, uint8_t* dst, int cw, int ch) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    std::lock_guard<std::recursive_mutex> hl(api_host_mutex());
+    if (sw < 0 || sh < 0 || cw < 0 || ch < 0 || sw > cw) return T3_E_ARG;
+    const uint64_t nb_in = (uint64_t)sw * sh * 3u, nb_out = (uint64_t)cw * ch * 3u;
+    if (!nb_out) return T3_OK;
+    if (!dst || (nb_in && !src)) return T3_E_ARG;
+    void *di, *dout; int rc = roundtrip(src, nb_in, &di, nb_out, &dout); if (rc) return rc;
+    rc = t3hip_blit_center_rgb_dev((const uint8_t*)di, sw, sh, (uint8_t*)dout, cw, ch, api_stream()); if (rc) return rc;
+    return fetch(dst, dout, nb_out);
+}
+int t3hip_extract_center_q(const void* full_px6, int fw, int fh, void* sub_px6, int sw, int sh) {
+    if (!api_ready()) return T3_E_NODEVICE;
+    std::lock_guard<std::recursive_mutex> hl(api_host_mutex());
+    if (fw < 0 || fh < 0 || sw < 0 || sh < 0 || sw > fw) return T3_E_ARG;
+    const uint64_t nb_in = (uint64_t)fw * fh * 6u, nb_out = (uint64_t)sw * sh * 6u;
+    if (!nb_out) return T3_OK;
+    if (!sub_px6 || (nb_in && !full_px6)) return T3_E_ARG;
+    void *di, *dout; int rc = roundtrip(full_px6, nb_in, &di, nb_out, &dout); if (rc) return rc;
+    rc = t3hip_extract_center_q_dev(di, fw, fh, dout, sw, sh, api_stream()); if (rc) return rc;
+    return fetch(sub_px6, dout, nb_out);
 }
 
 // measurement aid (profiles/copy_ceiling.py): a plain streaming kernel over the same byte volumes as a codec launch

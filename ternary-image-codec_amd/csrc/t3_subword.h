@@ -10,5 +10,7 @@ __global__ void base243_pack_kernel(const uint8_t* trits, uint64_t n_trits, uint
 __global__ void base243_unpack_kernel(const uint8_t* in, uint64_t n_bytes, uint64_t total, uint8_t* trits);
 __global__ void mod27_bytes_kernel(const uint8_t* in, uint64_t n, uint8_t* out);
 __global__ void stream_copy_kernel(const uint4* src, uint64_t n_read16, uint4* dst, uint64_t n_write16, int nt);
+__global__ void center_window_kernel(const uint8_t* src, uint64_t src_row_bytes, uint32_t sy0, uint64_t sx0, uint8_t* dst, uint64_t dst_row_bytes,
+                                     uint64_t dst_bytes, uint32_t dy0, uint32_t n_rows, uint64_t dx0, uint64_t row_bytes);
 #endif
 }  // namespace t3

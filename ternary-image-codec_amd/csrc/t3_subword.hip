@@ -213,4 +213,28 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const uint4* __restric
     if (nt) stream_copy_body<true>(src, n_read16, dst, n_write16); else stream_copy_body<false>(src, n_read16, dst, n_write16);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// centred window copy (io_image.hpp:125-140 blit_center_rgb, :215-235 extract_center_q): dst is a dst_rows x dst_row_bytes byte
+// image; rows [dy0, dy0 + n_rows) take bytes [dx0, dx0 + row_bytes) from source rows sy0 .. (source pitch src_row_bytes, read at
+// byte sx0), every other destination byte is zero.  One aligned destination dword per lane; the source bytes are gathered one by
+// one (rows of 3- and 6-byte elements start at any byte).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void center_window_kernel(const uint8_t* __restrict__ src, uint64_t src_row_bytes, uint32_t sy0, uint64_t sx0,
+                                                            uint8_t* __restrict__ dst, uint64_t dst_row_bytes, uint64_t dst_bytes,
+                                                            uint32_t dy0, uint32_t n_rows, uint64_t dx0, uint64_t row_bytes) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 4u;
+    for (uint64_t b0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4u; b0 < dst_bytes; b0 += stride) {
+        uint64_t y = b0 / dst_row_bytes, x = b0 - y * dst_row_bytes;
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            if (b0 + i < dst_bytes && y >= dy0 && y - dy0 < n_rows && x >= dx0 && x - dx0 < row_bytes)
+                v |= (uint32_t)src[(uint64_t)(sy0 + (uint32_t)(y - dy0)) * src_row_bytes + sx0 + (x - dx0)] << (8u * i);
+            if (++x == dst_row_bytes) { x = 0; ++y; }
+        }
+        if (b0 + 4 <= dst_bytes) *(uint32_t*)(dst + b0) = v;
+        else for (uint32_t i = 0; b0 + i < dst_bytes; ++i) dst[b0 + i] = (uint8_t)(v >> (8u * i));
+    }
+}
+
 }  // namespace t3

@@ -212,6 +212,16 @@ class _Lib:
         n = self._f("ut_to_base243", C.c_uint64)(_u8p(t), C.c_uint64(len(t)), _u8p(out))
         return out[:n].copy()
 
+    def blit_center_rgb(self, src, sw, sh, cw, ch):                       # io_image.hpp:125-140
+        s_ = np.ascontiguousarray(src, np.uint8).reshape(-1); out = np.zeros(cw * ch * 3, np.uint8)
+        self._f("blit_center_rgb", None)(_u8p(s_), C.c_int(sw), C.c_int(sh), _u8p(out), C.c_int(cw), C.c_int(ch))
+        return out
+
+    def extract_center_q(self, full, fw, fh, sw, sh):                     # io_image.hpp:215-235
+        f_ = np.ascontiguousarray(full).view(np.uint8).reshape(-1); out = np.zeros(sw * sh * 6, np.uint8)
+        self._f("extract_center_q", None)(_vp(f_), C.c_int(fw), C.c_int(fh), _vp(out), C.c_int(sw), C.c_int(sh))
+        return out
+
     def base243_to_ut(self, b):
         b = np.ascontiguousarray(b, np.uint8); out = np.zeros(len(b) * 5 + 8, np.uint8)
         n = self._f("base243_to_ut", C.c_int64)(_u8p(b), C.c_uint64(len(b)), _u8p(out))

@@ -384,6 +384,40 @@ def test_base243_and_wire_bytes_match_oracle(t3, orc, gpu):
 
 
 @pytest.mark.gpu
+def test_centring_blits_match_oracle(t3, orc, gpu):
+    """blit_center_rgb / extract_center_q (io_image.hpp:125-140, 215-235) against the oracle's restatement (parity unpinned:
+    io_image.hpp does not build here): smaller, equal, odd-sized, taller-than-canvas and empty cases, then an 8K canvas on
+    the device entry points."""
+    import torch
+    rng = np.random.default_rng(21)
+    for (sw, sh, cw, ch) in [(5, 3, 9, 8), (9, 8, 9, 8), (1, 1, 2, 2), (7, 11, 8, 5), (3, 20, 3, 7), (0, 0, 4, 4), (4, 4, 0, 0), (33, 17, 64, 64), (729, 486, 1024, 512)]:
+        src = rng.integers(0, 256, sw * sh * 3, dtype=np.uint8)
+        assert np.array_equal(t3.blit_center_rgb(src, sw, sh, cw, ch).reshape(-1), orc.blit_center_rgb(src, sw, sh, cw, ch)), (sw, sh, cw, ch)
+    with pytest.raises(t3.T3Error):
+        t3.blit_center_rgb(np.zeros(10 * 2 * 3, np.uint8), 10, 2, 8, 8)
+    for (fw, fh, sw, sh) in [(9, 8, 5, 3), (9, 8, 9, 8), (8, 5, 7, 11), (3, 7, 3, 20), (64, 64, 33, 17), (4, 4, 0, 0), (1024, 512, 729, 486)]:
+        full = rng.integers(0, 65536, fw * fh * 3, dtype=np.uint16)
+        got = np.asarray(t3.extract_center_q(full.view(np.uint8), fw, fh, sw, sh)).view(np.uint8).reshape(-1)
+        assert np.array_equal(got, orc.extract_center_q(full, fw, fh, sw, sh)), (fw, fh, sw, sh)
+    with pytest.raises(t3.T3Error):
+        t3.extract_center_q(np.zeros(4 * 4 * 6, np.uint8), 4, 4, 5, 2)
+    # 8K canvas: a 6561 x 4320 window (the S24 centred raster is narrower than the frame) blitted and cut back out
+    cw, ch, sw, sh = 7680, 4320, 6561, 4000
+    src = torch.from_numpy(rng.integers(0, 256, sw * sh * 3, dtype=np.uint8)).cuda()
+    canvas = torch.full((cw * ch * 3,), 7, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    t3.blit_center_rgb_dev(src.data_ptr(), sw, sh, canvas.data_ptr(), cw, ch, s)
+    c3 = canvas.view(ch, cw, 3); x0, y0 = (cw - sw) // 2, (ch - sh) // 2
+    assert torch.equal(c3[y0:y0 + sh, x0:x0 + sw].reshape(-1), src)
+    assert int(c3[:y0].max()) == 0 and int(c3[y0 + sh:].max()) == 0 and int(c3[:, :x0].max()) == 0 and int(c3[:, x0 + sw:].max()) == 0
+    q = torch.from_numpy(rng.integers(0, 256, cw * ch * 6, dtype=np.uint8)).cuda()
+    sub = torch.zeros(sw * sh * 6, dtype=torch.uint8, device="cuda")
+    t3.extract_center_q_dev(q.data_ptr(), cw, ch, sub.data_ptr(), sw, sh, s)
+    torch.cuda.synchronize()
+    assert torch.equal(sub.view(sh, sw, 6), q.view(ch, cw, 6)[y0:y0 + sh, x0:x0 + sw])
+
+
+@pytest.mark.gpu
 def test_subword_dev_entry_points_full_frame(t3, orc, gpu):
     """8K-frame sizes through the device entry points: extract -> build is the identity on the kept trits (S24)."""
     import torch

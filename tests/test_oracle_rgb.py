@@ -47,3 +47,16 @@ def test_quant_to_rgb_restatements_agree(orc):
     r = y + f(1.402) * cr; g = (y - f(0.344136) * cb) - f(0.714136) * cr; b = y + f(1.772) * cb
     want = np.stack([np.clip(_lround(v.astype(np.float64)), 0, 255) for v in (r, g, b)], axis=1).astype(np.uint8).reshape(-1)
     assert np.array_equal(orc.quant_to_rgb(px), want)
+
+
+def test_centring_blit_restatements_agree(orc):
+    """io_image.hpp:125-140 / 215-235 restated twice (C in oracle/, numpy slices here): parity unpinned, like the bridge."""
+    rng = np.random.default_rng(5)
+    for (sw, sh, cw, ch) in [(5, 3, 9, 8), (9, 8, 9, 8), (7, 11, 8, 5), (3, 20, 3, 7), (33, 17, 64, 64)]:
+        src = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+        want = np.zeros((ch, cw, 3), np.uint8); x0, y0 = max(0, (cw - sw) // 2), max(0, (ch - sh) // 2)
+        rows = min(sh, ch - y0); want[y0:y0 + rows, x0:x0 + sw] = src[:rows]
+        assert np.array_equal(orc.blit_center_rgb(src, sw, sh, cw, ch), want.reshape(-1))
+        full = rng.integers(0, 256, (ch, cw, 6), dtype=np.uint8)             # window sw x sh out of a cw x ch frame
+        want = np.zeros((sh, sw, 6), np.uint8); rows = min(sh, ch - y0); want[:rows] = full[y0:y0 + rows, x0:x0 + sw]
+        assert np.array_equal(orc.extract_center_q(full, cw, ch, sw, sh), want.reshape(-1))
