@@ -24,8 +24,20 @@ n_raw = NPX // 2; n_enc = t3.encoded_words(n_raw, cfg)
 coded = torch.zeros(n_enc * 9 + 64, dtype=torch.uint8, device="cuda")
 t3.encode_frame_dev(d_px.data_ptr(), NPX, cfg, coded.data_ptr(), n_enc, s)
 L = t3.plan(n_raw, cfg)
-if mode == "errors":
+if mode == "errors" and conf != "beacon":
     t3.inject_errors_dev(coded.data_ptr(), L.header_syms, L.body_syms // 26, 4242, (26 - max(L.band_k)) // 2, s)
+elif mode == "errors":   # the injector works on a contiguous body: hurt the beacon-free stream, then put its symbols between the beacons
+    cfg0 = t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=F)
+    n0 = t3.encoded_words(n_raw, cfg0); L0 = t3.plan(n_raw, cfg0)
+    plain = torch.zeros(n0 * 9 + 64, dtype=torch.uint8, device="cuda")
+    t3.encode_frame_dev(d_px.data_ptr(), NPX, cfg0, plain.data_ptr(), n0, s)
+    t3.inject_errors_dev(plain.data_ptr(), L0.header_syms, L0.body_syms // 26, 4242, 3, s)
+    torch.cuda.synchronize()
+    pos = torch.arange(L.body_syms_framed, device="cuda")
+    keep = ~((pos >= 4) & ((pos - 4) % (9 * 64) == 0))
+    idx = torch.nonzero(keep).reshape(-1)[: L.body_syms] + L.header_syms
+    coded[idx] = plain[L0.header_syms: L0.header_syms + L0.body_syms]
+    del pos, keep, idx
 out = torch.zeros(NPX * 6 + 64, dtype=torch.uint8, device="cuda")
 ver = torch.zeros(2, dtype=torch.int32, device="cuda")
 f = lambda: t3.decode_frame_async(coded.data_ptr(), n_enc, cfg, n_raw, out.data_ptr(), n_raw if words else NPX, ver.data_ptr(), not words, s)

@@ -268,9 +268,9 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
 
 int launch_fn(const void* fn, const EncLaunch& e, hipStream_t s) {
     // persistent grid = what is actually resident: workgroups/CU from the occupancy query (VGPR, LDS and wave limits)
-    static std::map<std::pair<const void*, uint64_t>, int> occ_cache; static std::mutex occ_mu;   // shared by every context (one device type)
+    static std::map<std::pair<const void*, uint64_t>, int> occ_cache; static std::mutex occ_mu;   // per device: the dynamic-LDS attribute is set on the device's copy of the function
     std::lock_guard<std::mutex> occ_lk(occ_mu);
-    const auto key = std::make_pair(fn, (uint64_t)e.block << 32 | e.a.lds_bytes);
+    const auto key = std::make_pair(fn, (uint64_t)(uint32_t)g.dev << 48 | (uint64_t)e.block << 32 | e.a.lds_bytes);
     auto it = occ_cache.find(key);
     if (it == occ_cache.end()) {
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -329,19 +329,21 @@ int launch_fn(const void* fn, const EncLaunch& e, hipStream_t s) {
 #endif
     return T3_OK;
 }
-template <int FE, bool IL> int launch_enc2(const EncLaunch& e, hipStream_t s) {
-    const void* fn = (const void*)encode_kernel_mixed<FE, IL>;
-    if (e.rsel == 1) fn = (const void*)encode_kernel_uep<FE, IL>;   // UEP on the matrix cores
+template <int FE, bool IL, bool BCN> int launch_enc2(const EncLaunch& e, hipStream_t s) {
+    const void* fn = BCN ? nullptr : (const void*)encode_kernel_mixed<FE, IL>;       // the LUT kernel has no fused beacon (the caller adds the pass)
+    if (e.rsel == 1) fn = (const void*)encode_kernel_uep<FE, IL, BCN>;   // UEP on the matrix cores
     else if (e.a.afrag) switch (e.rsel) {                      // single-k launches: matrix-core kernels (<= 640 threads)
-        case 2: fn = (const void*)encode_kernel_k<FE, IL, 2>; break;
-        case 4: fn = (const void*)encode_kernel_k<FE, IL, 4>; break;
-        case 6: fn = (const void*)encode_kernel_k<FE, IL, 6>; break;
-        case 8: fn = (const void*)encode_kernel_k<FE, IL, 8>; break;
+        case 2: fn = (const void*)encode_kernel_k<FE, IL, 2, BCN>; break;
+        case 4: fn = (const void*)encode_kernel_k<FE, IL, 4, BCN>; break;
+        case 6: fn = (const void*)encode_kernel_k<FE, IL, 6, BCN>; break;
+        case 8: fn = (const void*)encode_kernel_k<FE, IL, 8, BCN>; break;
         default: break;
     }
+    if (!fn) return T3_E_ARG;
     return launch_fn(fn, e, s);
 }
-template <int FE> int launch_enc(const EncLaunch& e, hipStream_t s) { return e.a.il_on ? launch_enc2<FE, true>(e, s) : launch_enc2<FE, false>(e, s); }
+template <int FE, bool IL> int launch_enc1(const EncLaunch& e, hipStream_t s) { return e.a.bcn_pb ? launch_enc2<FE, IL, true>(e, s) : launch_enc2<FE, IL, false>(e, s); }
+template <int FE> int launch_enc(const EncLaunch& e, hipStream_t s) { return e.a.il_on ? launch_enc1<FE, true>(e, s) : launch_enc1<FE, false>(e, s); }
 int launch_enc_fe(int fe, const EncLaunch& e, hipStream_t s) { return fe == FE_PIXELS ? launch_enc<FE_PIXELS>(e, s) : fe == FE_RGB ? launch_enc<FE_RGB>(e, s) : launch_enc<FE_WORDS>(e, s); }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
@@ -381,7 +383,10 @@ int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, vo
     const uint32_t hs = (uint32_t)header_encode(*cfg, n_raw, hdr);
     const uint32_t pad = (uint32_t)(9 * L.out_words - L.out_syms);
     uint8_t* body_out = (uint8_t*)d_out + hs; uint8_t* frame_out = (uint8_t*)d_out;
-    if (L.beacon_on) { void* p; rc = scratch(2, L.body_syms + 64, &p, s); if (rc) return rc; body_out = (uint8_t*)p; frame_out = nullptr; }
+    // A beacon (OLD:1118-1141) rides in the store addressing of the matrix-core kernels when one launch covers the frame and a 16-byte
+    // run can hold one beacon at most (period >= 2); otherwise the body goes to scratch and beacon_kernel frames it.
+    const bool bcn_cand = L.beacon_on && cfg->beacon_band_slot < 9 && cfg->beacon_words_period >= 2 && cfg->beacon_words_period < (1u << 27) && !getenv("T3HIP_BEACON_PASS");
+    bool bcn_fused = false;
     // group bands into launches: all together when the lcm of their k's keeps the tile small, else one launch per k
     uint32_t kmask = 0; for (int b = 0; b < 9; ++b) kmask |= 1u << k_index(L.band_k[b]);
     std::vector<uint32_t> groups;
@@ -410,6 +415,19 @@ int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, vo
             rc = get_lut(km, cfg->mode, &lut); if (rc) return rc;
             if (!plan_enc_group(L, *cfg, m, fe, *lut, e)) return T3_E_ARG;
         }
+        if (L.beacon_on) {
+            bcn_fused = bcn_cand && groups.size() == 1 && (mfma || uep);
+            if (bcn_fused) {
+                const uint64_t cyc = 9ull * cfg->beacon_words_period, pb = cyc - 1, B = L.body_syms, slot = cfg->beacon_band_slot;
+                e.a.bcn_slot = (uint32_t)slot; e.a.bcn_pb = (uint32_t)pb; e.a.bcn_div = to_dev(fastdiv((uint32_t)pb));
+                e.a.bcn_sym = beacon_symbol(cfg->profile, (uint16_t)(cfg->superframe_words % 5), 0);     // OLD:1130
+                // framed bytes after the last body byte (the rest of the last word): zeros, or a beacon whose slot comes after it
+                const uint64_t next = B ? B + (B - 1 < slot ? 0 : 1 + (B - 1 - slot) / pb) : 0;
+                e.a.bcn_tail_off = hs + next; e.a.bcn_tail_len = (uint32_t)(L.body_syms_framed - next); e.a.bcn_tail_vals = 0;
+                if (e.a.bcn_tail_len > 8) return T3_E_ARG;                                   // (cannot happen: less than one word)
+                for (uint64_t q = next; q < L.body_syms_framed; ++q) if (q >= slot && (q - slot) % cyc == 0) e.a.bcn_tail_vals |= (uint64_t)e.a.bcn_sym << (8 * (q - next));
+            } else { void* p; rc = scratch(2, L.body_syms + 64, &p, s); if (rc) return rc; body_out = (uint8_t*)p; frame_out = nullptr; }
+        }
         e.a.afrag = mfma ? lut->d_afrag : nullptr;
         e.a.in = (const uint8_t*)d_in; e.a.n_units = n_units; e.a.n_units_pad = fe_px(fe) ? 2 * n_raw : n_units;
         if (fe == FE_RGB) { rc = rgb_quant_table(&e.a.qt); if (rc) return rc; }
@@ -419,7 +437,7 @@ int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, vo
         if (rc) return rc;
         first = false;
     }
-    if (L.beacon_on) {
+    if (L.beacon_on && !bcn_fused) {
         BeaconArgs b; memset(&b, 0, sizeof b);
         b.body = body_out; b.frame_out = (uint8_t*)d_out; b.body_syms = L.body_syms; b.framed_syms = L.body_syms_framed;
         b.period = cfg->beacon_words_period; b.slot = cfg->beacon_band_slot;
@@ -669,6 +687,7 @@ int api_fail_hip(hipError_t e, const char* what) { return fail_hip(e, what); }
 uint32_t* api_flag() { return g.d_flag; }
 RsTables* api_tables() { return g.d_tab; }
 int api_n_cu() { return g.n_cu; }
+int api_device() { return g.dev; }
 std::recursive_mutex& api_host_mutex() { return g.host_mu; }
 void*& api_slot(int id) { return g.slot[id]; }
 }  // namespace t3

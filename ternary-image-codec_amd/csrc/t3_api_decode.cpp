@@ -18,7 +18,7 @@
 
 namespace t3 {
 int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr);
-int api_fail_hip(hipError_t e, const char* what); uint32_t* api_flag(); RsTables* api_tables(); int api_n_cu(); std::recursive_mutex& api_host_mutex();
+int api_fail_hip(hipError_t e, const char* what); uint32_t* api_flag(); RsTables* api_tables(); int api_n_cu(); int api_device(); std::recursive_mutex& api_host_mutex();
 void*& api_slot(int id);          // per-context object slots (t3_api.cpp): this file owns 0..31
 }  // namespace t3
 using namespace t3;
@@ -116,9 +116,10 @@ int rgb_dequant_tables(const uint8_t** out) {
     *out = d; return T3_OK;
 }
 
-// `body`: the coded stream with `hdr_syms` symbols of header in front of the band-serial body (the caller has stripped a beacon)
+// `body`: the coded stream with `hdr_syms` symbols of header in front of the band-serial body; bcn_period != 0: the body still carries
+// its beacon symbols (slot bcn_slot of every bcn_period-th word, OLD:952-957) and the loads step over them
 int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_syms, const t3_layout& L, const ScrCycle& sc,
-                       void* d_out, uint64_t units, int to_pixels, uint32_t* d_fail, hipStream_t s) {
+                       void* d_out, uint64_t units, int to_pixels, uint32_t* d_fail, hipStream_t s, uint32_t bcn_slot = 0, uint32_t bcn_period = 0) {
     if (L.interleave2d || L.n_raw_words == 0) return 1;
     std::lock_guard<std::mutex> lk(g_tab_mu);
     for (int b = 1; b < 9; ++b) if (L.band_k[b] != L.band_k[0]) return 1;
@@ -134,6 +135,8 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
     for (int b = 0; b < 9; ++b) { a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b]; a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6); maxb = std::max<uint64_t>(maxb, L.band_blocks[b]); }
     a.n_tiles = (uint32_t)((maxb + a.nb - 1) / a.nb);
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
+    const bool bcn = bcn_period != 0;
+    if (bcn) { a.bcn_slot = bcn_slot; a.bcn_pb = 9u * bcn_period - 1u; a.bcn_div = to_dev(fastdiv(a.bcn_pb)); }
     a.fma = d_fma;
     const uint32_t ybytes = (a.TS + 16u + 15u) & ~15u;
     if (to_pixels) {   // [hdr][fold 512][T16 1024][FMA][A operand][Y0][Y1][Q0][Q1]
@@ -153,22 +156,25 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
     }
     const void* fn = nullptr;
     switch (26 - k) {
-#define T3_PICK(R) (rgb ? (const void*)decode_fixed_px_kernel<R, true> : to_pixels ? (const void*)decode_fixed_px_kernel<R, false> : (const void*)decode_fixed_kernel<R>)
+#define T3_PICKB(R, B) (rgb ? (const void*)decode_fixed_px_kernel<R, true, B> : to_pixels ? (const void*)decode_fixed_px_kernel<R, false, B> : (const void*)decode_fixed_kernel<R, B>)
+#define T3_PICK(R) (bcn ? T3_PICKB(R, true) : T3_PICKB(R, false))
         case 2: fn = T3_PICK(2); break;
         case 4: fn = T3_PICK(4); break;
         case 6: fn = T3_PICK(6); break;
         default: fn = T3_PICK(8); break;
 #undef T3_PICK
+#undef T3_PICKB
     }
-    static std::map<const void*, int> occ;
-    auto it = occ.find(fn);
+    static std::map<std::pair<const void*, int>, int> occ;          // per device (the attribute is set on the device's copy of the function)
+    const auto okey = std::make_pair(fn, api_device());
+    auto it = occ.find(okey);
     if (it == occ.end()) {
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int o = 1; HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, 512, a.lds_bytes));
         // measured on MI355X (stamp build, workgroup start times): LDS is handed out in 1280-byte units, 128 per CU; the occupancy
         // query does not round, and a persistent grid sized one workgroup per CU too large runs its last third after the rest
         o = std::min<int>(o, (int)(128u / ((a.lds_bytes + 1279u) / 1280u)));
-        it = occ.emplace(fn, std::max(1, o)).first;
+        it = occ.emplace(okey, std::max(1, o)).first;
     }
     const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(a.n_tiles, (uint32_t)(api_n_cu() * it->second)));
 #ifdef T3_DEC_STAMPS
@@ -201,8 +207,8 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
 unsigned grid_for(uint64_t items, unsigned block) { return (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, (items + block - 1) / block), 1u << 20); }
 
 int occupancy_of(const void* fn, int threads, uint32_t lds_bytes, int* out) {
-    static std::map<std::pair<const void*, uint32_t>, int> occ;
-    auto key = std::make_pair(fn, lds_bytes);
+    static std::map<std::pair<const void*, uint64_t>, int> occ;     // per device
+    auto key = std::make_pair(fn, (uint64_t)(uint32_t)api_device() << 32 | lds_bytes);
     auto it = occ.find(key);
     if (it == occ.end()) {
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -316,17 +322,23 @@ int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_r
         if (want_rgb && (cap_units > 2 * n_words || cap_units + 1 < 2 * n_words || L.interleave2d)) return 1;
         if (want_rgb) { for (int b = 1; b < 9; ++b) if (L.band_k[b] != L.band_k[0]) return 1; }
         if (funits <= cap_units && (!to_pixels || ((uintptr_t)d_out & 15u) == 0) && getenv("T3HIP_GENERIC_DECODE") == nullptr && 9 * n_in < (1ull << 32)) {
-            // a beacon is stripped first (its own pass); then the fully fused kernel where it applies, else the two-kernel path
+            // the fully fused kernel where it applies (a beacon is stepped over in its loads); else a beacon is stripped by its own pass,
+            // and the two-kernel path takes the rest
             const uint8_t* body = (const uint8_t*)d_in; uint64_t body_bytes = 9 * n_in; uint32_t hs = L.header_syms;
-            if (L.beacon_on) {
-                void* d_b; int brc = api_scratch(2, L.body_syms + 64, &d_b, s); if (brc) return brc;
-                DebeaconArgs d; d.framed = (const uint8_t*)d_in + L.header_syms; d.framed_bytes = 9 * n_in - L.header_syms; d.body = (uint8_t*)d_b; d.body_syms = L.body_syms; d.period = cfg.beacon_words_period; d.slot = cfg.beacon_band_slot;
-                if (L.body_syms) { hipLaunchKernelGGL(debeacon_kernel, dim3(grid_for((L.body_syms + 15) / 16, 256)), dim3(256), 0, s, d); HIPCHK(hipGetLastError()); }
-                body = (const uint8_t*)d_b; body_bytes = L.body_syms; hs = 0;
+            const bool bcn_ok = L.beacon_on && cfg.beacon_band_slot < 9 && cfg.beacon_words_period >= 2 && cfg.beacon_words_period < (1u << 27) && getenv("T3HIP_BEACON_PASS") == nullptr;
+            int frc = 1;
+            if (bcn_ok) frc = decode_fixed_fused(body, body_bytes, hs, L, sc, d_out, funits, to_pixels, d_fail, s, cfg.beacon_band_slot, cfg.beacon_words_period);
+            if (frc == 1) {
+                if (L.beacon_on) {
+                    void* d_b; int brc = api_scratch(2, L.body_syms + 64, &d_b, s); if (brc) return brc;
+                    DebeaconArgs d; d.framed = (const uint8_t*)d_in + L.header_syms; d.framed_bytes = 9 * n_in - L.header_syms; d.body = (uint8_t*)d_b; d.body_syms = L.body_syms; d.period = cfg.beacon_words_period; d.slot = cfg.beacon_band_slot;
+                    if (L.body_syms) { hipLaunchKernelGGL(debeacon_kernel, dim3(grid_for((L.body_syms + 15) / 16, 256)), dim3(256), 0, s, d); HIPCHK(hipGetLastError()); }
+                    body = (const uint8_t*)d_b; body_bytes = L.body_syms; hs = 0;
+                }
+                if (!bcn_ok) frc = decode_fixed_fused(body, body_bytes, hs, L, sc, d_out, funits, to_pixels, d_fail, s);
+                if (frc == 1 && want_rgb) return 1;
+                if (frc == 1) frc = decode_fixed_stream(body, body_bytes, hs, cfg, L, sc, d_out, funits, to_pixels, d_fail, s);
             }
-            int frc = decode_fixed_fused(body, body_bytes, hs, L, sc, d_out, funits, to_pixels, d_fail, s);
-            if (frc == 1 && want_rgb) return 1;
-            if (frc == 1) frc = decode_fixed_stream(body, body_bytes, hs, cfg, L, sc, d_out, funits, to_pixels, d_fail, s);
             if (frc == T3_OK) { *n_out = funits; return T3_OK; }
             if (frc < 0) return frc;
         }

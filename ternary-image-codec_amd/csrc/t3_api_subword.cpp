@@ -91,12 +91,13 @@ int t3hip_mod27_bytes_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, void*
 // copies sw * 3 bytes into a cw * 3 byte row there (it runs over the following rows and, on the last one, off the buffer).
 int t3hip_blit_center_rgb_dev(const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int cw, int ch, void* stream) {
     if (!api_ready()) return T3_E_NODEVICE;
-    if (sw < 0 || sh < 0 || cw < 0 || ch < 0 || sw > cw) return T3_E_ARG;
+    if (sw < 0 || sh < 0 || cw < 0 || ch < 0) return T3_E_ARG;
     const uint64_t dst_bytes = (uint64_t)cw * (uint64_t)ch * 3u;
     if (!dst_bytes) return T3_OK;
+    const uint32_t y0 = (uint32_t)(ch > sh ? (ch - sh) / 2 : 0), rows = (uint32_t)(sh < ch - (int)y0 ? sh : ch - (int)y0);
+    if (rows && sw > cw) return T3_E_ARG;
     if (!d_dst || ((uintptr_t)d_dst & 3u) || ((uint64_t)sw * sh && !d_src)) return T3_E_ARG;
-    const uint32_t x0 = (uint32_t)((cw - sw) / 2), y0 = (uint32_t)(ch > sh ? (ch - sh) / 2 : 0);
-    const uint32_t rows = (uint32_t)(sh < ch - (int)y0 ? sh : ch - (int)y0);
+    const uint32_t x0 = (uint32_t)(cw > sw ? (cw - sw) / 2 : 0);
     hipLaunchKernelGGL(center_window_kernel, dim3(blocks_for((dst_bytes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_src, (uint64_t)sw * 3u, 0u, (uint64_t)0,
                        d_dst, (uint64_t)cw * 3u, dst_bytes, y0, rows, (uint64_t)x0 * 3u, (uint64_t)sw * 3u);
     HIPCHK(hipGetLastError()); return T3_OK;
@@ -105,12 +106,13 @@ int t3hip_blit_center_rgb_dev(const uint8_t* d_src, int sw, int sh, uint8_t* d_d
 // zero (the reference's resize()).  A window wider than the frame is refused (the reference reads on into the next frame row).
 int t3hip_extract_center_q_dev(const void* d_full_px6, int fw, int fh, void* d_sub_px6, int sw, int sh, void* stream) {
     if (!api_ready()) return T3_E_NODEVICE;
-    if (fw < 0 || fh < 0 || sw < 0 || sh < 0 || sw > fw) return T3_E_ARG;
+    if (fw < 0 || fh < 0 || sw < 0 || sh < 0) return T3_E_ARG;
     const uint64_t dst_bytes = (uint64_t)sw * (uint64_t)sh * 6u;
     if (!dst_bytes) return T3_OK;
+    const uint32_t y0 = (uint32_t)(fh > sh ? (fh - sh) / 2 : 0), rows = (uint32_t)(sh < fh - (int)y0 ? sh : fh - (int)y0);
+    if (rows && sw > fw) return T3_E_ARG;
     if (!d_sub_px6 || ((uintptr_t)d_sub_px6 & 3u) || ((uint64_t)fw * fh && !d_full_px6)) return T3_E_ARG;
-    const uint32_t x0 = (uint32_t)((fw - sw) / 2), y0 = (uint32_t)(fh > sh ? (fh - sh) / 2 : 0);
-    const uint32_t rows = (uint32_t)(sh < fh - (int)y0 ? sh : fh - (int)y0);
+    const uint32_t x0 = (uint32_t)(fw > sw ? (fw - sw) / 2 : 0);
     hipLaunchKernelGGL(center_window_kernel, dim3(blocks_for((dst_bytes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_full_px6, (uint64_t)fw * 6u, y0,
                        (uint64_t)x0 * 6u, (uint8_t*)d_sub_px6, (uint64_t)sw * 6u, dst_bytes, 0u, rows, (uint64_t)0, (uint64_t)sw * 6u);
     HIPCHK(hipGetLastError()); return T3_OK;
@@ -190,7 +192,7 @@ int t3hip_mod27_bytes(const uint8_t* in, uint64_t n, uint8_t* out) {
 int t3hip_blit_center_rgb(const uint8_t* src, int sw, int sh, uint8_t* dst, int cw, int ch) {
     if (!api_ready()) return T3_E_NODEVICE;
     std::lock_guard<std::recursive_mutex> hl(api_host_mutex());
-    if (sw < 0 || sh < 0 || cw < 0 || ch < 0 || sw > cw) return T3_E_ARG;
+    if (sw < 0 || sh < 0 || cw < 0 || ch < 0) return T3_E_ARG;
     const uint64_t nb_in = (uint64_t)sw * sh * 3u, nb_out = (uint64_t)cw * ch * 3u;
     if (!nb_out) return T3_OK;
     if (!dst || (nb_in && !src)) return T3_E_ARG;
@@ -201,7 +203,7 @@ int t3hip_blit_center_rgb(const uint8_t* src, int sw, int sh, uint8_t* dst, int 
 int t3hip_extract_center_q(const void* full_px6, int fw, int fh, void* sub_px6, int sw, int sh) {
     if (!api_ready()) return T3_E_NODEVICE;
     std::lock_guard<std::recursive_mutex> hl(api_host_mutex());
-    if (fw < 0 || fh < 0 || sw < 0 || sh < 0 || sw > fw) return T3_E_ARG;
+    if (fw < 0 || fh < 0 || sw < 0 || sh < 0) return T3_E_ARG;
     const uint64_t nb_in = (uint64_t)fw * fh * 6u, nb_out = (uint64_t)sw * sh * 6u;
     if (!nb_out) return T3_OK;
     if (!sub_px6 || (nb_in && !full_px6)) return T3_E_ARG;

@@ -99,6 +99,7 @@ struct DecFx2Args {
     uint32_t band_blocks[9]; uint64_t band_body_off[9]; uint32_t band_boff6[9];
     uint32_t cyc24, pre0, pre1;
     uint32_t y_off, y_stride, q_off, q_stride, o_off, af_off, lds_bytes;   // px kernel: two symbol buffers / queues, y_stride / q_stride apart
+    uint32_t bcn_slot, bcn_pb; DevDiv bcn_div;   // BCN kernels: a beacon symbol sits in front of body byte bcn_slot + j bcn_pb (bcn_pb = 9 period - 1 >= 17); `in` is the framed stream
     const uint8_t* dq; uint32_t dq_off;          // RGB out (row f1 fused): dequantiser tables yd[244] | cd[84] (t3_rgb.h) and their LDS offset
     uint64_t* dbg;                             // diagnostic stamp builds only (T3_DEC_STAMPS); null in the product
 };
@@ -137,8 +138,8 @@ void decode_shutdown();                       // frees what decode_init and the 
 
 #if defined(__HIPCC__)
 __global__ void dec_gather_rs_kernel(const DecArgs a);
-template <int R> __global__ void decode_fixed_kernel(const DecFx2Args a);
-template <int R, bool RGB> __global__ void decode_fixed_px_kernel(const DecFx2Args a);
+template <int R, bool BCN> __global__ void decode_fixed_kernel(const DecFx2Args a);        // BCN: beacon symbols stepped over in the loads
+template <int R, bool RGB, bool BCN> __global__ void decode_fixed_px_kernel(const DecFx2Args a);
 __global__ void decode_stream_kernel(const DecStArgs a);
 template <bool TO_PIXELS> __global__ void emit_stream_kernel(const EmitStArgs a);
 __global__ void debeacon_kernel(const DebeaconArgs a);

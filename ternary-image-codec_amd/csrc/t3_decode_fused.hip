@@ -36,6 +36,44 @@ __device__ __forceinline__ void barrier_lds2() { asm volatile("s_waitcnt lgkmcnt
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(2))) V4a2 { v4u32 v; };
 __device__ __forceinline__ v4u32 load16(const uint8_t* p) { return ((const V4a2*)p)->v; }
+
+// A lane's 16 coded bytes, in flight.  BCN (beacon stripped in the loads, OLD:952-957): the run starts at framed offset
+// g0 + (beacons in front of it); if the next beacon falls inside the run (after c < 16 body bytes) the run is 17 framed bytes long and
+// x carries the 17th byte and c; run_bytes() closes the gap when the run is used.
+template <bool BCN> struct Run { v4u32 w; };
+template <> struct Run<true> { v4u32 w; uint32_t w4, x; };              // five aligned dwords that hold the (up to) 17 framed bytes; x = start byte | c << 8
+template <bool BCN>
+__device__ __forceinline__ Run<BCN> load_run(const DecFx2Args& a, const uint8_t* body, const uint32_t g0) {
+    Run<BCN> r;
+    if constexpr (!BCN) r.w = load16(body + g0);          // 2-byte aligned: as fast as aligned dwords (measured); odd addresses are not, hence:
+    else {
+        uint32_t nb0 = 0, c = a.bcn_slot - g0;
+        if (g0 >= a.bcn_slot) { const uint32_t u = g0 - a.bcn_slot, j = __umulhi(u, a.bcn_div.mul) >> a.bcn_div.sh; nb0 = j + 1u; c = a.bcn_pb - (u - j * a.bcn_pb); }
+        const uintptr_t p = (uintptr_t)(body + (g0 + nb0));
+        const uint32_t* q = (const uint32_t*)(p & ~(uintptr_t)3);                    // aligned dwords (the stream starts 16-byte aligned: t3hip.h)
+        r.w = *(const v4u32*)q; r.w4 = 0;
+        if (((uint32_t)p & 3u) != 0u || c < 16u) r.w4 = q[4];                          // (never a dword that lies wholly behind the run's last byte)
+        r.x = ((uint32_t)p & 3u) | min(c, 16u) << 8;
+    }
+    return r;
+}
+template <bool BCN>
+__device__ __forceinline__ void run_bytes(const Run<BCN>& r, uint32_t (&L)[4]) {
+    if constexpr (!BCN) { L[0] = r.w[0]; L[1] = r.w[1]; L[2] = r.w[2]; L[3] = r.w[3]; }
+    else {
+        const uint32_t sh = r.x & 3u, c = r.x >> 8, dc = c >> 2, bc = c & 3u;        // dc == 4: no beacon in the run
+        uint32_t F[5];
+        F[0] = __builtin_amdgcn_alignbyte(r.w[1], r.w[0], sh); F[1] = __builtin_amdgcn_alignbyte(r.w[2], r.w[1], sh);
+        F[2] = __builtin_amdgcn_alignbyte(r.w[3], r.w[2], sh); F[3] = __builtin_amdgcn_alignbyte(r.w4, r.w[3], sh);
+        F[4] = r.w4 >> (8u * sh);                                                     // its low byte: the 17th framed byte
+        const uint32_t D = dc == 0u ? F[0] : dc == 1u ? F[1] : dc == 2u ? F[2] : F[3], Dn = dc == 0u ? F[1] : dc == 1u ? F[2] : dc == 2u ? F[3] : F[4];
+        const uint32_t sel = bc == 0u ? 0x04030201u : bc == 1u ? 0x04030200u : bc == 2u ? 0x04030100u : 0x04020100u;   // v_perm(S0, S1): 0..3 = S1, 4..7 = S0
+        const uint32_t Mx = __builtin_amdgcn_perm(Dn, D, sel);                       // the dword the beacon sits in, without it
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) L[i] = i < dc ? F[i] : i == dc ? Mx : __builtin_amdgcn_alignbyte(F[i + 1], F[i], 1u);
+    }
+}
+
 __device__ __forceinline__ uint32_t mod3u(uint32_t x) { return x - 3u * (uint32_t)(((uint64_t)x * 0xAAAAAAABull) >> 33); }
 
 // constants -> LDS (both kernels): band rows, counters, byte tables, fold tables, T, multiply-accumulate table, A operand
@@ -117,7 +155,7 @@ __device__ __forceinline__ void fx2_pixels12(const DecFx2Args& a, const uint32_t
 // ------------------------------------------------------------------------------------------------------------------
 // pixels out: producer / consumer waves
 // ------------------------------------------------------------------------------------------------------------------
-template <int R, bool RGB>
+template <int R, bool RGB, bool BCN>
 __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_px_kernel(const DecFx2Args a) {
     constexpr uint32_t TCOP = 16, TBASE = kFx2TPx, MT = kFx2ModPx, QCAP = kFx2QCap;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,18 +184,20 @@ __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_px_kern
             return fx2_block<R>(g, tb, mod3u(tb), y_off);
         };
         // lanes without a block read the first bytes of the body (always there) and ignore them
-        auto src_of = [&](const Blk& b) -> const uint8_t* { return body + (b.valid ? b.off + 10u * h : 0u); };
-        v4u32 PA = {0, 0, 0, 0}, PB = {0, 0, 0, 0};                                // the next pass's two sets, in flight
-        if (n_my) { PA = load16(src_of(blk(0, 0, blockIdx.x, 0))); PB = load16(src_of(blk(0, 1, blockIdx.x, 0))); }
+        auto run_of = [&](const Blk& b) -> Run<BCN> { return load_run<BCN>(a, body, b.valid ? b.off + 10u * h : 0u); };
+        Run<BCN> PA, PB;                                                           // the next pass's two sets, in flight
+        PA.w = v4u32{0, 0, 0, 0}; PB.w = PA.w; if constexpr (BCN) { PA.x = 16u << 8; PB.x = PA.x; PA.w4 = 0; PB.w4 = 0; }
+        if (n_my) { PA = run_of(blk(0, 0, blockIdx.x, 0)); PB = run_of(blk(0, 1, blockIdx.x, 0)); }
         for (uint32_t k = 0; k < n_my; ++k) {
             const uint32_t tile = blockIdx.x + k * grid, buf = k & 1u;
             const uint32_t y_off = a.y_off + buf * a.y_stride, q_off = a.q_off + buf * a.q_stride;
 #pragma unroll
             for (uint32_t pass = 0; pass < 2; ++pass) {
-                const uint32_t LA[4] = {PA[0], PA[1], PA[2], PA[3]}, LB[4] = {PB[0], PB[1], PB[2], PB[3]};
+                uint32_t LA[4], LB[4];
+                run_bytes<BCN>(PA, LA); run_bytes<BCN>(PB, LB);
                 {   // the next pass's input: in flight under this pass (the producers issue no stores, so it is waited for alone)
                     const uint32_t np = pass ^ 1u, nt = pass == 0 ? tile : tile + grid;
-                    if (nt < a.n_tiles) { PA = load16(src_of(blk(np, 0, nt, 0))); PB = load16(src_of(blk(np, 1, nt, 0))); }
+                    if (nt < a.n_tiles) { PA = run_of(blk(np, 0, nt, 0)); PB = run_of(blk(np, 1, nt, 0)); }
                 }
                 if (wave * 128u + pass * 64u >= n_items) continue;                   // (wave-uniform) nothing left of the tile for this pass
                 const Blk bA = blk(pass, 0, tile, y_off), bB = blk(pass, 1, tile, y_off);
@@ -219,7 +259,7 @@ __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_px_kern
 // ------------------------------------------------------------------------------------------------------------------
 // raw words out: the phases one after the other
 // ------------------------------------------------------------------------------------------------------------------
-template <int R>
+template <int R, bool BCN>
 __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_kernel(const DecFx2Args a) {
     constexpr uint32_t TCOP = 32, TBASE = kFx2TSeq, MT = kFx2ModSeq;
     const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -231,25 +271,27 @@ __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_kernel(
     const uint32_t n = lane & 31u, h = lane >> 5;
     const Geo gA0 = fx2_geo(wave * 64u + n, n_items, a.nb, a.div_nb), gB0 = fx2_geo(wave * 64u + 32u + n, n_items, a.nb, a.div_nb);
     Geo gA = gA0, gB = gB0;
-    auto src_of = [&](const Blk& b) -> const uint8_t* { return body + (b.valid ? b.off + 10u * h : 0u); };
-    v4u32 PA = {0, 0, 0, 0}, PB = {0, 0, 0, 0};                                    // this wave's two sets of the current tile, prefetched
+    auto run_of = [&](const Blk& b) -> Run<BCN> { return load_run<BCN>(a, body, b.valid ? b.off + 10u * h : 0u); };
+    Run<BCN> PA, PB;                                                               // this wave's two sets of the current tile, prefetched
+    PA.w = v4u32{0, 0, 0, 0}; PB.w = PA.w; if constexpr (BCN) { PA.x = 16u << 8; PB.x = PA.x; PA.w4 = 0; PB.w4 = 0; }
     if (blockIdx.x < a.n_tiles) {
-        PA = load16(src_of(fx2_block<R>(gA, blockIdx.x * a.nb, mod3u(blockIdx.x * a.nb), a.y_off)));
-        PB = load16(src_of(fx2_block<R>(gB, blockIdx.x * a.nb, mod3u(blockIdx.x * a.nb), a.y_off)));
+        PA = run_of(fx2_block<R>(gA, blockIdx.x * a.nb, mod3u(blockIdx.x * a.nb), a.y_off));
+        PB = run_of(fx2_block<R>(gB, blockIdx.x * a.nb, mod3u(blockIdx.x * a.nb), a.y_off));
     }
     uint32_t par = 0;
     for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x, par ^= 1u) {
         const uint32_t tb = tile * a.nb, t3 = mod3u(tb);
         asm volatile("" : "+v"(gA), "+v"(gB));                                     // opaque: keeps the unpacked pieces out of loop-long registers
         const Blk bA = fx2_block<R>(gA, tb, t3, a.y_off), bB = fx2_block<R>(gB, tb, t3, a.y_off);
-        const uint32_t LA[4] = {PA[0], PA[1], PA[2], PA[3]}, LB[4] = {PB[0], PB[1], PB[2], PB[3]};
+        uint32_t LA[4], LB[4];
+        run_bytes<BCN>(PA, LA); run_bytes<BCN>(PB, LB);
         const Synd sA = fx2_set<R, TCOP, TBASE, MT>(bA, LA, lane, a.af_off, a.cyc24, a.pre0, a.pre1);
         const Synd sB = fx2_set<R, TCOP, TBASE, MT>(bB, LB, lane, a.af_off, a.cyc24, a.pre0, a.pre1);
         {   // the next tile's input, in flight under this tile's correction phase
             const uint32_t nt = tile + gridDim.x;
             if (nt < a.n_tiles) {
-                PA = load16(src_of(fx2_block<R>(gA, nt * a.nb, mod3u(nt * a.nb), a.y_off)));
-                PB = load16(src_of(fx2_block<R>(gB, nt * a.nb, mod3u(nt * a.nb), a.y_off)));
+                PA = run_of(fx2_block<R>(gA, nt * a.nb, mod3u(nt * a.nb), a.y_off));
+                PB = run_of(fx2_block<R>(gB, nt * a.nb, mod3u(nt * a.nb), a.y_off));
             }
         }
         fx2_own_blocks<R>(a.roots, a.fma_off, a.fail, sA, sB, bA, bB, (h ? gB0 : gA0) & 0xFFFFu, lane, kFx2Cnt + 4u * par, a.q_off, 512u);
@@ -262,7 +304,8 @@ __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_kernel(
         barrier_lds2();
         // the loads are waited for BEFORE this tile's stores are issued (vmcnt completes in order, stores count too): they have had
         // the correction phase to land, and the wait does not cover the acknowledgement of stores issued a moment ago
-        asm volatile("" : "+v"(PA), "+v"(PB));
+        asm volatile("" : "+v"(PA.w), "+v"(PB.w));
+        if constexpr (BCN) asm volatile("" : "+v"(PA.x), "+v"(PB.x), "+v"(PA.w4), "+v"(PB.w4));
         const uint64_t unit0 = (uint64_t)tile * units_tile;
         const uint32_t n_here = (uint32_t)min((uint64_t)units_tile, a.n_units > unit0 ? a.n_units - unit0 : 0ull);
         const uint32_t ng = a.TS / 26u;                                            // groups of 26 symbols -> 3 words (OLD:1022-1040)
@@ -273,8 +316,9 @@ __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_kernel(
     }
 }
 
-#define T3_INST_DEC(R) template __global__ void decode_fixed_kernel<R>(const DecFx2Args); template __global__ void decode_fixed_px_kernel<R, false>(const DecFx2Args); \
-    template __global__ void decode_fixed_px_kernel<R, true>(const DecFx2Args);
+#define T3_INST_DECB(R, BCN) template __global__ void decode_fixed_kernel<R, BCN>(const DecFx2Args); template __global__ void decode_fixed_px_kernel<R, false, BCN>(const DecFx2Args); \
+    template __global__ void decode_fixed_px_kernel<R, true, BCN>(const DecFx2Args);
+#define T3_INST_DEC(R) T3_INST_DECB(R, false) T3_INST_DECB(R, true)
 T3_INST_DEC(2) T3_INST_DEC(4) T3_INST_DEC(6) T3_INST_DEC(8)
 
 }  // namespace t3

@@ -66,6 +66,10 @@ struct EncArgs {
     uint32_t  p1_wpp;               // phase 1 (pixels): waves that cover a tile (one lane = four pixel triples)
     uint32_t  qt_off;               // FE_RGB: LDS offset of the chroma quantiser table (256 bytes: C -> Cq + 40, io_image.hpp:73-76)
     const uint8_t* qt;              // ... and its device image
+    // beacon insertion fused into the stores (BCN kernels, OLD:1118-1141): a beacon symbol sits in front of body byte bcn_slot + j bcn_pb
+    // (bcn_pb = 9 period - 1 >= 17), the stores go to framed offsets; the few framed bytes after the last body byte come from the host
+    uint32_t  bcn_slot, bcn_pb, bcn_sym; DevDiv bcn_div;
+    uint32_t  bcn_tail_len; uint64_t bcn_tail_off, bcn_tail_vals;   // frame_out offset, up to 8 byte values (low byte first)
     uint64_t* dbg;                  // diagnostic stamp builds only (T3_STAMPS); null in the product
 };
 

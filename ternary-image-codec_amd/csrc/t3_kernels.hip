@@ -372,6 +372,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 struct __attribute__((packed, aligned(2))) U32a2 { uint32_t v; };
 struct __attribute__((packed, aligned(2))) U128a2 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(1))) U128a1 { uint32_t v[4]; };
 constexpr uint32_t kMfmaModOff = 3 * 4096, kMfmaScr = 336;     // must match t3_host.hpp; scrambler dwords sit in the LDS header
 
 // How the (up to) two sets of a call map to blocks: set s covers items item0[s] .. item0[s] + 31 of a run of n_items blocks
@@ -379,7 +380,7 @@ constexpr uint32_t kMfmaModOff = 3 * 4096, kMfmaScr = 336;     // must match t3_
 // index -> band bytes (UEP groups) or ~0 for the identity (one k on all nine bands).
 struct P2Map { uint32_t item0[2]; uint32_t n_items, nb; DevDiv div_nb; uint32_t band_tab, scr_off; };
 
-template <int R, bool GRP>      // GRP: UEP group call (one set, band table, the group's scrambler dwords); else one k on all nine bands (two sets)
+template <int R, bool GRP, bool BCN>      // BCN: beacon insertion fused into the stores; GRP: UEP group call (one set, band table, the group's scrambler dwords); else one k on all nine bands (two sets)
 __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t symb, uint32_t tile, uint32_t lane, const v4i (&Afr)[3], const P2Map& M) {
     constexpr uint32_t K = 26 - R, H = R / 2;
     constexpr uint32_t TB = GRP ? kLdsHdrUep : kLdsHdr, MB = TB + kMfmaModOff;
@@ -473,12 +474,36 @@ __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t symb,
         E.v[1] = __builtin_amdgcn_perm(q23[0], q01[1], selE);
         E.v[2] = __builtin_amdgcn_perm(q23[1], q23[0], selE);
         E.v[3] = __builtin_amdgcn_perm(tail, q23[1], selE);                        // h=1: bytes 22..25
+        if constexpr (BCN) {
+            // The run's 16 body bytes start at body offset g0; nb0 beacons lie in front of it in the framed stream and the next one
+            // comes after c more body bytes.  c < 16: it falls inside the run, whose bytes from c on move up by one (the 17th
+            // byte goes out on its own); c == bcn_pb with a beacon directly in front of the run (only a block's first run can
+            // have no run before it that holds that beacon): this lane writes it.  bcn_pb >= 17: one beacon per run at most.
+            const uint32_t g0 = (uint32_t)s.goff + 10u * h;                       // body symbols are 31-bit (plan_layout)
+            uint32_t nb0 = 0, c = a.bcn_slot - g0;
+            if (g0 >= a.bcn_slot) { const uint32_t u = g0 - a.bcn_slot, j = fdiv(u, a.bcn_div); nb0 = j + 1u; c = a.bcn_pb - (u - j * a.bcn_pb); }
+            const bool inside = c < 16u, pre = nb0 != 0u && c == a.bcn_pb;
+            const uint32_t dc = inside ? c >> 2 : 4u, bc = c & 3u;
+            const uint32_t Ed = dc == 0u ? E.v[0] : dc == 1u ? E.v[1] : dc == 2u ? E.v[2] : E.v[3];
+            const uint32_t sel = bc == 0u ? 0x02010004u : bc == 1u ? 0x02010400u : bc == 2u ? 0x02040100u : 0x04020100u;
+            const uint32_t Mx = __builtin_amdgcn_perm(a.bcn_sym, Ed, sel);        // low bc bytes, the beacon, the rest one byte up
+            U128a1 F;
+            F.v[0] = dc == 0u ? Mx : E.v[0];
+#pragma unroll
+            for (uint32_t i = 1; i < 4; ++i) F.v[i] = i < dc ? E.v[i] : i == dc ? Mx : __builtin_amdgcn_alignbyte(E.v[i], E.v[i - 1], 3u);
+            uint8_t* dst = a.body_out + (s.goff + 10u * h + nb0);
+            const bool extra = s.valid && (inside || pre);
+            if (s.valid) *(U128a1*)dst = F;                                         // any byte alignment
+            const bool any_extra = __builtin_amdgcn_ballot_w64(extra) != 0;
+            if (any_extra) { if (extra) *(inside ? dst + 16 : dst - 1) = (uint8_t)(inside ? E.v[3] >> 24 : a.bcn_sym); }
+            return (__builtin_amdgcn_ballot_w64(s.valid) != 0 ? 1u : 0u) + (any_extra ? 1u : 0u);
+        }
 #ifdef T3_ABL_NO_STORE
         if (s.valid && a.n_tiles == 0xFFFFFFFFu)
 #else
         if (s.valid)
 #endif
-            *(U128a2*)(a.body_out + s.goff + 10u * h) = E;                         // 2-byte aligned
+            *(U128a2*)(a.body_out + s.goff + 10u * h) = E;                         // 2-byte aligned (measured: as fast as 16-byte aligned)
 #ifndef T3_ABL_NO_STORE
         return __builtin_amdgcn_ballot_w64(s.valid) != 0 ? 1u : 0u;               // a store with no active lane is branched over
 #else
@@ -785,7 +810,7 @@ __device__ __forceinline__ void barrier_input(uint32_t younger) {
 
 // RSEL = 26-k when every band of the launch shares one k (the common case: no dead code paths, fewer registers,
 // 640-thread bound so that two workgroups share a CU); RSEL = 0 handles mixed k with a wave-uniform switch.
-template <int FE, bool IL, int RSEL>
+template <int FE, bool IL, int RSEL, bool BCN>
 __device__ __forceinline__ void encode_body(const EncArgs& a) {
     constexpr uint32_t GS = fe_px(FE) ? kGroupSyms : kGroupSymsW;      // symbols per lane group
     constexpr uint32_t GBf = FE == FE_PIXELS ? kGroupBytes : FE == FE_RGB ? kGroupBytesRgb : kGroupBytesW;
@@ -832,6 +857,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             for (uint32_t i = 0; i < 96; ++i) if (i < a.hdr_syms) a.frame_out[i] = a.hdr[i];
         }
         if (tid < a.pad_bytes) a.frame_out[a.out_syms + tid] = 0;
+        if constexpr (BCN) { if (tid < a.bcn_tail_len) a.frame_out[a.bcn_tail_off + tid] = (uint8_t)(a.bcn_tail_vals >> (8u * tid)); }   // after the last body byte
     }
 
     v4i Afr[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};                   // single-k kernels: the parity matrix lives in 12 VGPRs
@@ -1008,7 +1034,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             if constexpr (RSEL > 1) {                                          // one k on all nine bands: both sets of the wave in one call
                 P2Map M; M.item0[0] = wave * 64u; M.item0[1] = wave * 64u + 32u; M.n_items = a.n_items; M.nb = a.nb_uniform; M.div_nb = a.div_nb;
                 M.band_tab = ~0u; M.scr_off = kMfmaScr;
-                younger = phase2_mfma<RSEL, false>(a, symb, tile, lane, Afr, M);
+                younger = phase2_mfma<RSEL, false, BCN>(a, symb, tile, lane, Afr, M);
             } else if constexpr (RSEL == 1) {                                  // UEP: a set lies inside one group of bands that share k
                 younger = 0;
 #pragma unroll
@@ -1027,10 +1053,10 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 #pragma unroll
                     for (int s = 0; s < 3; ++s) Ag[s] = *T3_LDS_PTR(v4i, ao + 16u * (s * 64u + lane));
                     switch (rr) {
-                        case 2: younger += phase2_mfma<2, true>(a, symb, tile, lane, Ag, M); break;
-                        case 4: younger += phase2_mfma<4, true>(a, symb, tile, lane, Ag, M); break;
-                        case 6: younger += phase2_mfma<6, true>(a, symb, tile, lane, Ag, M); break;
-                        default: younger += phase2_mfma<8, true>(a, symb, tile, lane, Ag, M); break;
+                        case 2: younger += phase2_mfma<2, true, BCN>(a, symb, tile, lane, Ag, M); break;
+                        case 4: younger += phase2_mfma<4, true, BCN>(a, symb, tile, lane, Ag, M); break;
+                        case 6: younger += phase2_mfma<6, true, BCN>(a, symb, tile, lane, Ag, M); break;
+                        default: younger += phase2_mfma<8, true, BCN>(a, symb, tile, lane, Ag, M); break;
                     }
                 }
             } else if (item < a.n_items) {
@@ -1071,17 +1097,18 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 #ifndef T3_ENC_WAVES_PER_EU
 #define T3_ENC_WAVES_PER_EU 6   // <= 80 VGPRs: three 8-wave workgroups per CU
 #endif
-template <int FE, bool IL, int RSEL>
-__global__ __launch_bounds__(512, T3_ENC_WAVES_PER_EU) void encode_kernel_k(const EncArgs a) { encode_body<FE, IL, RSEL>(a); }
+template <int FE, bool IL, int RSEL, bool BCN>
+__global__ __launch_bounds__(512, T3_ENC_WAVES_PER_EU) void encode_kernel_k(const EncArgs a) { encode_body<FE, IL, RSEL, BCN>(a); }
+template <int FE, bool IL, bool BCN>
+__global__ __launch_bounds__(512, T3_ENC_WAVES_PER_EU) void encode_kernel_uep(const EncArgs a) { encode_body<FE, IL, 1, BCN>(a); }   // UEP on the matrix cores
 template <int FE, bool IL>
-__global__ __launch_bounds__(512, T3_ENC_WAVES_PER_EU) void encode_kernel_uep(const EncArgs a) { encode_body<FE, IL, 1>(a); }   // UEP on the matrix cores
-template <int FE, bool IL>
-__global__ __launch_bounds__(1024) void encode_kernel_mixed(const EncArgs a) { encode_body<FE, IL, 0>(a); }
+__global__ __launch_bounds__(1024) void encode_kernel_mixed(const EncArgs a) { encode_body<FE, IL, 0, false>(a); }
 
-#define T3_INST_K(FE, IL) \
-    template __global__ void encode_kernel_k<FE, IL, 2>(const EncArgs); template __global__ void encode_kernel_k<FE, IL, 4>(const EncArgs); \
-    template __global__ void encode_kernel_k<FE, IL, 6>(const EncArgs); template __global__ void encode_kernel_k<FE, IL, 8>(const EncArgs); \
-    template __global__ void encode_kernel_mixed<FE, IL>(const EncArgs); template __global__ void encode_kernel_uep<FE, IL>(const EncArgs);
+#define T3_INST_KB(FE, IL, BCN) \
+    template __global__ void encode_kernel_k<FE, IL, 2, BCN>(const EncArgs); template __global__ void encode_kernel_k<FE, IL, 4, BCN>(const EncArgs); \
+    template __global__ void encode_kernel_k<FE, IL, 6, BCN>(const EncArgs); template __global__ void encode_kernel_k<FE, IL, 8, BCN>(const EncArgs); \
+    template __global__ void encode_kernel_uep<FE, IL, BCN>(const EncArgs);
+#define T3_INST_K(FE, IL) T3_INST_KB(FE, IL, false) T3_INST_KB(FE, IL, true) template __global__ void encode_kernel_mixed<FE, IL>(const EncArgs);
 T3_INST_K(FE_PIXELS, false) T3_INST_K(FE_PIXELS, true) T3_INST_K(FE_WORDS, false) T3_INST_K(FE_WORDS, true) T3_INST_K(FE_RGB, false) T3_INST_K(FE_RGB, true)
 
 // ---------------------------------------------------------------------------------------------------------

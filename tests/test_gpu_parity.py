@@ -522,6 +522,52 @@ def test_rgb_bridge_inverse(t3, orc, gpu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [0, 1])
+def test_beacon_in_the_store_addressing(gpu, orc, mode, monkeypatch):
+    """Beacon insertion fused into the encode kernels' stores (OLD:1118-1141): every slot, short and long periods (period 1 keeps
+    the separate pass), one k and luma UEP, 1-D and 2-D, pixel counts that end the body before / at / after the last word's beacon
+    slot -- against the oracle, and against the separate beacon pass (T3HIP_BEACON_PASS) on the same input."""
+    rng = np.random.default_rng(77 + mode)
+    case = 0
+    for period in (1, 2, 3, 5, 7, 64, 83, 300):
+        for slot in range(9):
+            case += 1
+            uep = [2, 1, 1, 0, 2, 3, 1, 0, 2][case % 9] if case % 3 else [int(x) for x in rng.integers(0, 4, 9)]
+            kw = dict(profile=4 if case % 4 == 0 else 1, uep=uep, tile=(int(rng.integers(1, 90)), int(rng.integers(1, 30))) if case % 4 == 0 else (0, 0),
+                      beacon=(period, slot, 1), seed=(case, 7 * case + 1, 3))
+            cfg, ocfg = both(gpu, kw, mode)
+            n = int(rng.integers(1, 12000)) if case % 5 else int(rng.integers(0, 40))
+            px = rand_pixels(rng, n)
+            ok, enc = gpu.encode_frame(px, cfg)
+            rc, want = orc.encode_frame(px, ocfg, cap=n + 64)
+            assert ok and rc == 0 and enc.shape == want.shape and np.array_equal(enc, want), (kw, n)
+            if case % 6 == 0:
+                monkeypatch.setenv("T3HIP_BEACON_PASS", "1")
+                ok2, enc2 = gpu.encode_frame(px, cfg)
+                monkeypatch.delenv("T3HIP_BEACON_PASS")
+                assert ok2 and np.array_equal(enc2, enc), (kw, n)
+            if mode == 1:       # ... and stepped over in the fused decoder's loads: up to t errors in every block of the beaconed stream
+                L = gpu.plan((n + 1) // 2, cfg)
+                flat = enc.reshape(-1).copy(); hs = L.header_syms
+                pos = np.arange(L.body_syms_framed)
+                body_idx = np.flatnonzero(~((pos >= slot) & ((pos - slot) % (9 * period) == 0)))[: L.body_syms]
+                body = np.zeros((L.body_syms + 8) // 9 * 9, np.uint8); body[: L.body_syms] = flat[hs + body_idx]
+                hurt = np.asarray(orc.inject_errors(body.reshape(-1, 9), 0, L.body_syms // 26, 99 + case, (26 - max(L.band_k)) // 2)).reshape(-1)
+                flat[hs + body_idx] = hurt[: L.body_syms]
+                bad = flat.reshape(-1, 9)
+                padded = np.zeros(2 * ((n + 1) // 2), ol.PIXEL_DT); padded[:n] = px
+                for env in ((None,) if case % 4 else (None, "1")):
+                    if env: monkeypatch.setenv("T3HIP_BEACON_PASS", env)
+                    okd, back = gpu.decode_frame(bad, gpu.DecoderContext(mode=1))
+                    okr, rawback = gpu.decode_profile_to_raw(bad, gpu.DecoderContext(mode=1))
+                    if env: monkeypatch.delenv("T3HIP_BEACON_PASS")
+                    assert okd and np.array_equal(back, padded), (kw, n, env)
+                    assert okr and np.array_equal(np.asarray(rawback).reshape(-1), np.asarray(orc.pack_pixels(padded)).reshape(-1)), (kw, n, env)
+                rc, oback = orc.decode_frame(bad, ol.make_cfg(mode=1))
+                assert rc == 0 and np.array_equal(oback, padded), (kw, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
 def test_encode_frame_random_configurations(gpu, orc, mode):
     """Seeded fuzz over the configuration space (all four codes per band, 1-D / 2-D with odd tile shapes, beacons, seeds)
     and over pixel counts around the kernels' tile sizes (a single-k tile is 9 * 55 * k symbols ~ 2285 / 2057 / 2513 / 2742 px)."""
