@@ -43,9 +43,11 @@ res.append(run("C2 FIXED RS(26,20) 1-D (fused decoder), clean stream", t3.make_c
 res.append(run("FIXED luma-priority UEP 1-D (two-kernel decoder), clean", t3.make_cfg(profile=P.P3_RS26_20, uep="luma", mode=F)))
 res.append(run("FIXED 2-D 64x64 RS(26,20) (two-kernel decoder), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(64, 64), mode=F)))
 res.append(run("C3 FIXED 2-D 64x64 + luma UEP (two-kernel decoder), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F)))
-res.append(run("C2 FIXED + beacon every 64 words (strip pass + fused decoder), clean", t3.make_cfg(profile=P.P3_RS26_20, uep=2, beacon=(64, 4, 1), mode=F)))
+res.append(run("C2 FIXED + beacon every 64 words (stepped over in the fused decoder's loads), clean", t3.make_cfg(profile=P.P3_RS26_20, uep=2, beacon=(64, 4, 1), mode=F)))
 res.append(run("C2 FIXED RS(26,20) 1-D (fused decoder), 0..3 errors per block", t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=F), errors=True))
 res.append(run("C3 FIXED 2-D 64x64 + luma UEP (two-kernel decoder), 0..2 errors per block", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F), errors=True))
 res.append(run("C2 FIXED RS(26,20) 1-D (fused decoder) to raw words, clean stream", t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=F), words=True))
 res.append(run("C3 FIXED 2-D 64x64 + luma UEP (two-kernel decoder) to raw words, clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F), words=True))
+res.append(run("FIXED 1-D four different k per frame (two-kernel decoder), clean", t3.make_cfg(profile=P.P3_RS26_20, uep=[0, 1, 2, 3, 0, 1, 2, 3, 0], mode=F)))
+res.append(run("FIXED 2-D wide rows 7680x8 RS(26,20) (two-kernel decoder), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(7680, 8), mode=F)))
 print(json.dumps(res, indent=1))

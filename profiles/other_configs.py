@@ -38,5 +38,10 @@ res.append(run("C3 P5 2-D 64x64 + luma-priority UEP (mixed k)", t3.make_cfg(prof
 res.append(run("P5 2-D 64x64, RS(26,20) all bands", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(64, 64))))
 res.append(run("RS(26,24) all bands 1-D", t3.make_cfg(profile=P.P1_RS26_24, uep=0)))
 res.append(run("RS(26,18) all bands 1-D", t3.make_cfg(profile=P.P4_RS26_18, uep=3)))
-res.append(run("C2 + beacon every 64 words", t3.make_cfg(profile=P.P3_RS26_20, uep=2, beacon=(64, 4, 1))))
+res.append(run("C2 + beacon every 64 words (fused into the stores)", t3.make_cfg(profile=P.P3_RS26_20, uep=2, beacon=(64, 4, 1))))
+res.append(run("1-D luma-priority UEP (two k)", t3.make_cfg(profile=P.P3_RS26_20, uep="luma")))
+res.append(run("1-D four different k per frame (bands 24,22,20,18,...)", t3.make_cfg(profile=P.P3_RS26_20, uep=[0, 1, 2, 3, 0, 1, 2, 3, 0])))
+res.append(run("2-D wide rows 1024x16, RS(26,20) all bands", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(1024, 16))))
+res.append(run("2-D wide rows 7680x8, RS(26,20) all bands", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(7680, 8))))
+res.append(run("2-D odd tile 7x5, RS(26,20) all bands", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(7, 5))))
 print(json.dumps(res, indent=1))

@@ -325,6 +325,7 @@ int launch_fn(const void* fn, const EncLaunch& e, hipStream_t s) {
           fprintf(stderr, "[t3 stamps]   timeline (us from first start): last start=%.2f first end=%.2f last end=%.2f  WGs starting >10us late=%d\n", (s1 - s0) * 0.01, (e0 - s0) * 0.01, (e1 - s0) * 0.01, late);
           fprintf(stderr, "[t3 stamps]   lds_bytes=%u block=%u\n", e.a.lds_bytes, e.block); }
         fprintf(stderr, "[t3 stamps]   p1 split (wave 0): prefetch issue=%.0f convert=%.0f barrier wait=%.0f\n", acc[6] / grid, acc[7] / grid, acc[1] / grid);
+        { double il = 0; for (uint32_t w = 0; w < grid; ++w) il += (double)h16[16 * w + 10]; fprintf(stderr, "[t3 stamps]   2-D permutation pass (in p2): %.0f\n", il / grid); }
     }
 #endif
     return T3_OK;

@@ -224,7 +224,6 @@ int decode_fixed_stream(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_s
     if (L.n_raw_words == 0 || L.n_sym + (1u << 20) >= (1ull << 32) || body_bytes + hdr_syms >= (1ull << 32)) return 1;
     if (getenv("T3HIP_GENERIC_DECODE") != nullptr) return 1;
     const bool il = L.interleave2d != 0;
-    if (il && cfg.tile_w > 4096) return 1;                                  // a span's rows are staged in LDS
     std::lock_guard<std::mutex> lk(g_tab_mu);
     DecStArgs a; memset(&a, 0, sizeof a);
     // bands grouped by k, in order of first appearance
@@ -280,7 +279,7 @@ int decode_fixed_stream(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_s
         e.div_A = to_dev(fastdiv(e.il_A)); e.div_w = to_dev(fastdiv(e.il_w));
         e.il_fast = (e.il_w % 16u == 0 && (e.il_A % 16u == 0 || e.il_A == L.n_sym)) ? 1 : 0;
     }
-    e.sym_off = 0; e.o_off = (e.span + 2u * e.il_w + 64u + 15u) & ~15u;
+    e.sym_off = 0; e.o_off = (e.span + 64u + 15u) & ~15u;
     e.lds_bytes = e.o_off + (to_pixels ? 0u : (e.span / 26u) * 27u + 64u);
     const void* fn = to_pixels ? (const void*)emit_stream_kernel<true> : (const void*)emit_stream_kernel<false>;
     rc = occupancy_of(fn, 512, e.lds_bytes, &occ); if (rc) return rc;

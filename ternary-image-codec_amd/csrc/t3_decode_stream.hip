@@ -126,34 +126,28 @@ __global__ __launch_bounds__(512, 2) void emit_stream_kernel(const EmitStArgs a)
     const uint32_t units_step = TO_PIXELS ? (a.span / 13u) * 3u : (a.span / 26u) * 3u;
     for (uint32_t step = blockIdx.x; step < a.n_steps; step += gridDim.x) {
         const uint32_t U0 = step * a.span, U1 = (uint32_t)min((uint64_t)U0 + a.span, (uint64_t)a.n_sym);
-        uint32_t lo = U0, hi = U1;
-        if (a.il_on) {
-            uint32_t rl, rn, od;
-            row_of(U0, a, rl, rn, od); lo = rl;
-            row_of(U1 - 1u, a, rl, rn, od); hi = rl + rn;
-        }
-        const uint32_t lo16 = lo & ~15u;
-        auto at = [&](uint32_t v) -> uint32_t { return a.sym_off + (v - lo16); };   // LDS address of stream symbol v
+        // The de-interleave map is an involution inside every row segment (odd rows reversed, OLD:782-813): the step's pre-interleave
+        // symbols [U0, U1) are gathered straight from their mirrored places in the corrected stream, whatever the row width -- nothing
+        // but the step itself is read or staged.
+        auto at = [&](uint32_t v) -> uint32_t { return a.sym_off + (v - U0); };     // LDS address of pre-interleave symbol v (U0: 16-byte aligned)
         if (!a.il_on) {
-            for (uint32_t v = lo16 + 16u * tid; v < hi; v += 16u * nthr) *(uint4*)(lds + at(v)) = *(const uint4*)(a.ystream + v);
+            for (uint32_t v = U0 + 16u * tid; v < U1; v += 16u * nthr) *(uint4*)(lds + at(v)) = *(const uint4*)(a.ystream + v);
         } else if (a.il_fast) {
             // rows and chunks are multiples of 16 symbols: a 16-byte granule stays inside one row; an odd row reverses it
-            for (uint32_t v = lo + 16u * tid; v < hi; v += 16u * nthr) {
+            for (uint32_t v = U0 + 16u * tid; v < U1; v += 16u * nthr) {
                 uint32_t rl, rn, od; row_of(v, a, rl, rn, od);
-                const uint4 q = *(const uint4*)(a.ystream + v);
-                if (!od) *(uint4*)(lds + at(v)) = q;
+                if (!od) *(uint4*)(lds + at(v)) = *(const uint4*)(a.ystream + v);
                 else if (rn == a.il_w) {
-                    const uint32_t d = rl + (a.il_w - 16u - (v - rl));
-                    *(uint4*)(lds + at(d)) = make_uint4(__builtin_bswap32(q.w), __builtin_bswap32(q.z), __builtin_bswap32(q.y), __builtin_bswap32(q.x));
+                    const uint4 q = *(const uint4*)(a.ystream + (rl + (a.il_w - 16u - (v - rl))));
+                    *(uint4*)(lds + at(v)) = make_uint4(__builtin_bswap32(q.w), __builtin_bswap32(q.z), __builtin_bswap32(q.y), __builtin_bswap32(q.x));
                 } else {                                                        // the stream's last, shorter row
-                    const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
-                    for (uint32_t i = 0; i < 16u && v + i < rl + rn; ++i) lds[at(rl + (rn - 1u - (v + i - rl)))] = (uint8_t)(w4[i >> 2] >> (8u * (i & 3u)));
+                    for (uint32_t i = 0; i < 16u && v + i < rl + rn; ++i) lds[at(v + i)] = a.ystream[rl + (rn - 1u - (v + i - rl))];
                 }
             }
         } else {
-            for (uint32_t v = lo + tid; v < hi; v += nthr) {
+            for (uint32_t v = U0 + tid; v < U1; v += nthr) {
                 uint32_t rl, rn, od; row_of(v, a, rl, rn, od);
-                lds[at(od ? rl + (rn - 1u - (v - rl)) : v)] = a.ystream[v];
+                lds[at(v)] = a.ystream[od ? rl + (rn - 1u - (v - rl)) : v];
             }
         }
         __syncthreads();

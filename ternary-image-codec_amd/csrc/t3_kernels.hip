@@ -1003,6 +1003,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
                     for (uint32_t g = tid; 4u * g < TS; g += nthr) one_dword(S0 + 4u * g);
                 }
                 barrier_lds();
+                T3_STAMP(3);
                 symb = stage;
             }
         } else {
@@ -1088,7 +1089,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     if (tid == 0 && a.dbg) {
         uint64_t* d = a.dbg + 16ull * blockIdx.x;
         d[8] = __builtin_amdgcn_s_getreg(31 << 11 | 4); d[9] = __builtin_amdgcn_s_getreg(31 << 11 | 20);   // HW_ID, XCC_ID
-        d[0] = st_acc[0]; d[1] = st_acc[1]; d[2] = st_acc[2]; d[3] = st_rt0;
+        d[0] = st_acc[0]; d[1] = st_acc[1]; d[2] = st_acc[2] + st_acc[3]; d[3] = st_rt0; d[10] = st_acc[3];
         d[4] = __builtin_amdgcn_s_memtime() - st_t0; d[5] = __builtin_amdgcn_s_memrealtime() - st_rt0; d[6] = st_acc[4]; d[7] = st_acc[5];
     }
 #endif
