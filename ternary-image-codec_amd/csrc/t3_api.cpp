@@ -165,9 +165,13 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     uint64_t Lk = 2;
     for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) Lk = Lk / gcd64(Lk, L.band_k[b]) * L.band_k[b];
     uint32_t lut_bytes = lut.bytes;
-    // 2-D through the pipelined flow: a tile's input then covers the row segments it overlaps (up to w - 1 extra symbols each side)
-    const bool il_async = L.interleave2d && fe_px(fe) && cfg.tile_w <= 512;
-    const uint32_t il_extra = il_async ? 2u * cfg.tile_w : 0u;
+    // 2-D through the pipelined flow (pixel / RGB input): rows up to 512 symbols -- a tile's input covers the row segments it overlaps (up to
+    // w - 1 extra symbols each side) and a permutation pass follows phase 1 (il_async 1); wider rows -- the tile's pre-interleave symbols
+    // are up to three runs, staged one behind the other at 1-KiB pitches, and phase 1 stores each symbol at its post-interleave place
+    // (il_async 2; t3_kernels.hip, il_runs)
+    const uint32_t il_async = !(L.interleave2d && fe_px(fe)) ? 0u : cfg.tile_w <= 512 ? 1u : 2u;
+    const uint32_t il_extra = il_async == 1u ? 2u * cfg.tile_w : 0u;
+    const uint32_t il_stage = il_async == 2u ? 2u * (1024u + 4u * GB + 32u) : 0u;   // two more runs: their rounding and pitch
     const uint32_t hdr = grp ? (uint32_t)kLdsHdrUep : (uint32_t)kLdsHdr;
     bool mixed = false;
     { int k0 = 0; for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) { if (!k0) k0 = L.band_k[b]; else if (k0 != L.band_k[b]) mixed = true; } }
@@ -189,16 +193,16 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
             waves = (blocks_total + 63) / 64;                          // lanes are dealt to blocks linearly across bands
             uint32_t sets = 0;
             if (grp) {
-                for (int i = 0; i < 4; ++i) { uint32_t items = 0; for (int b = 0; b < 9; ++b) if (k_index(L.band_k[b]) == i) items += (uint32_t)(Lq / L.band_k[b]); sets += (items + 31) / 32; }
+                for (int i = 0; i < 4; ++i) { uint32_t items = 0; for (int b = 0; b < 9; ++b) if ((band_mask >> b & 1) && k_index(L.band_k[b]) == i) items += (uint32_t)(Lq / L.band_k[b]); sets += (items + 31) / 32; }
                 if (sets > (uint32_t)kMaxSets || pass > 0) break;
                 waves = 8;
             }
             if (waves > (pass == 0 ? 8u : (uint32_t)kMaxWaves)) break;   // pass 0: 512-thread workgroups, three per CU
-            const uint32_t groups = (uint32_t)((9 * Lq + il_extra) / GS) + 8, stage = groups * GB + 1024 + 32;   // +1 KiB: LDS-DMA pieces are whole
+            const uint32_t groups = (uint32_t)((9 * Lq + il_extra) / GS) + 8, stage = groups * GB + 1024 + 32 + il_stage;   // +1 KiB: LDS-DMA pieces are whole
             const uint32_t total = hdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq) + il_extra) + kSymBack + ((L.interleave2d && !il_async) ? 1u : 2u) * round16(stage) + (fe == FE_RGB ? 256u : 0u);
             if (total > budget) break;
             // wave-instructions per stream symbol: phase 2 costs ~180 per wave, phase 1 (pixels) ~120 per wave-iteration
-            const uint32_t wpp = p1_waves_per_parity((uint32_t)(9 * Lq) + il_extra);
+            const uint32_t wpp = p1_waves_per_parity((uint32_t)(9 * Lq) + il_extra + (il_async == 2u ? 312u : 0u));   // (three runs: up to six lane units of rounding)
             if (fe_px(fe) && wpp > std::max(waves, 4u)) continue;
             // UEP kernel: the phases are barrier-separated and a wave runs its sets one after the other, so a tile costs one
             // phase-1 pass plus ceil(sets / 8) set times, whatever the number of busy waves
@@ -228,10 +232,10 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     }
     a.n_items = nw; a.n_tiles = n_tiles;
     { uint32_t acc = 0; for (int b = 0; b < 9; ++b) { a.band_first[b] = acc; acc += a.band_nb_tile[b]; } a.band_first[9] = acc; }
-    a.stage_stride = round16(a.stage_groups * GB + 1024 + 32);
+    a.stage_stride = round16(a.stage_groups * GB + 1024 + 32 + il_stage);
     a.lds_bytes = a.stage_off + ((L.interleave2d && !il_async) ? 1u : 2u) * a.stage_stride;   // pipelined flow: two stage buffers (the next tile streams in early)
     if (fe == FE_RGB) { a.qt_off = a.lds_bytes; a.lds_bytes += 256u; }                            // chroma quantiser table of the fused bridge
-    a.il_async = il_async ? 1u : 0u;
+    a.il_async = il_async;
     a.n_sym = (uint32_t)L.n_sym;
     const ScrCycle sc = scrambler_cycle(cfg.seed_a, cfg.seed_b, cfg.seed_s0);
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
@@ -243,7 +247,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
         a.div_A = to_dev(fastdiv(a.il_A)); a.div_w = to_dev(fastdiv(a.il_w));
     }
     out.block = 64u * std::max<uint32_t>((nw + 63) / 64, 4u);
-    a.p1_wpp = p1_waves_per_parity(9 * Lq + il_extra);
+    a.p1_wpp = p1_waves_per_parity(9 * Lq + il_extra + (il_async == 2u ? 312u : 0u));
     out.rsel = 0;
     { int k0 = 0; bool same = true; for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) { if (!k0) k0 = L.band_k[b]; else if (k0 != L.band_k[b]) same = false; } if (same && k0 && band_mask == 0x1FF) out.rsel = 26 - k0; }
     a.nb_uniform = out.rsel ? a.band_nb_tile[0] : 0u; a.div_nb = to_dev(fastdiv(a.nb_uniform ? a.nb_uniform : 1u));
@@ -253,7 +257,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
         for (int i = 0; i < 4; ++i) {
             EncArgs::Grp& G = a.grp[ng]; memset(&G, 0, sizeof G);
             uint32_t nbands = 0;
-            for (int b = 0; b < 9; ++b) if (k_index(L.band_k[b]) == i) G.bands[nbands++] = (uint8_t)b;
+            for (int b = 0; b < 9; ++b) if ((band_mask >> b & 1) && k_index(L.band_k[b]) == i) G.bands[nbands++] = (uint8_t)b;
             if (!nbands) continue;
             G.nb = Lq / (uint32_t)kOfIndex[i]; G.div_nb = to_dev(fastdiv(G.nb)); G.n_items = nbands * G.nb; G.r = 26u - (uint32_t)kOfIndex[i];
             G.afrag_off = hdr + lut.k_off[i];
@@ -330,7 +334,7 @@ int launch_fn(const void* fn, const EncLaunch& e, hipStream_t s) {
 #endif
     return T3_OK;
 }
-template <int FE, bool IL, bool BCN> int launch_enc2(const EncLaunch& e, hipStream_t s) {
+template <int FE, int IL, bool BCN> int launch_enc2(const EncLaunch& e, hipStream_t s) {
     const void* fn = BCN ? nullptr : (const void*)encode_kernel_mixed<FE, IL>;       // the LUT kernel has no fused beacon (the caller adds the pass)
     if (e.rsel == 1) fn = (const void*)encode_kernel_uep<FE, IL, BCN>;   // UEP on the matrix cores
     else if (e.a.afrag) switch (e.rsel) {                      // single-k launches: matrix-core kernels (<= 640 threads)
@@ -343,8 +347,12 @@ template <int FE, bool IL, bool BCN> int launch_enc2(const EncLaunch& e, hipStre
     if (!fn) return T3_E_ARG;
     return launch_fn(fn, e, s);
 }
-template <int FE, bool IL> int launch_enc1(const EncLaunch& e, hipStream_t s) { return e.a.bcn_pb ? launch_enc2<FE, IL, true>(e, s) : launch_enc2<FE, IL, false>(e, s); }
-template <int FE> int launch_enc(const EncLaunch& e, hipStream_t s) { return e.a.il_on ? launch_enc1<FE, true>(e, s) : launch_enc1<FE, false>(e, s); }
+template <int FE, int IL> int launch_enc1(const EncLaunch& e, hipStream_t s) { return e.a.bcn_pb ? launch_enc2<FE, IL, true>(e, s) : launch_enc2<FE, IL, false>(e, s); }
+template <int FE> int launch_enc(const EncLaunch& e, hipStream_t s) {     // kernel flavour of the 2-D flow: see encode_body (raw words: always 1)
+    if (!e.a.il_on) return launch_enc1<FE, 0>(e, s);
+    if constexpr (FE != FE_WORDS) { if (e.a.il_async == 2u) return launch_enc1<FE, 2>(e, s); }
+    return launch_enc1<FE, 1>(e, s);
+}
 int launch_enc_fe(int fe, const EncLaunch& e, hipStream_t s) { return fe == FE_PIXELS ? launch_enc<FE_PIXELS>(e, s) : fe == FE_RGB ? launch_enc<FE_RGB>(e, s) : launch_enc<FE_WORDS>(e, s); }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
@@ -371,7 +379,7 @@ int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, vo
     t3_layout L; int rc = plan(n_raw, *cfg, L); if (rc != T3_OK) return rc;
     *n_out = L.out_words;
     // the fused RGB front end rides the pipelined flow only: RAW mode and 2-D rows wider than 512 go through the bridge kernel (1 = not taken)
-    if (fe == FE_RGB && (cfg->profile == T3_RAW_MODE || (L.interleave2d && cfg->tile_w > 512))) return 1;
+    if (fe == FE_RGB && cfg->profile == T3_RAW_MODE) return 1;
     if (L.out_words > cap_words) return T3_E_CAPACITY;
     if (L.out_words && !d_out) return T3_E_ARG;
     if (cfg->profile == T3_RAW_MODE) {                                   // OLD:1046-1050: out = in
@@ -396,7 +404,12 @@ int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, vo
         const LutImage* lut; rc = get_lut(kmask, cfg->mode, &lut); if (rc) return rc;
         EncLaunch e;
         if (single_k || plan_enc_group(L, *cfg, 0x1FF, fe, *lut, e)) groups.push_back(0x1FF);
-        else for (int i = 0; i < 4; ++i) if (kmask >> i & 1) { uint32_t m = 0; for (int b = 0; b < 9; ++b) if (k_index(L.band_k[b]) == i) m |= 1u << b; groups.push_back(m); }
+        else {
+            for (int i = 0; i < 4; ++i) if (kmask >> i & 1) { uint32_t m = 0; for (int b = 0; b < 9; ++b) if (k_index(L.band_k[b]) == i) m |= 1u << b; groups.push_back(m); }
+            // three or four different k: the lcm of all of them makes a tile no LDS holds, the lcm of two does -- the bands go in two
+            // launches of the matrix-core UEP kernel, by pairs of k (each launch runs phase 1 over the whole frame and encodes its bands)
+            if (groups.size() >= 3) { std::vector<uint32_t> pr; for (size_t i = 0; i < groups.size(); i += 2) pr.push_back(groups[i] | (i + 1 < groups.size() ? groups[i + 1] : 0u)); groups.swap(pr); }
+        }
     }
     bool first = true;
     for (uint32_t m : groups) {
@@ -404,8 +417,8 @@ int encode_dev(int fe, const void* d_in, uint64_t n_units, const t3_cfg* cfg, vo
         bool mfma = single_k && m == 0x1FF;
         const LutImage* lut; EncLaunch e;
         bool uep = false;
-        if (!single_k && m == 0x1FF) {                                   // several k, one launch: try the matrix-core UEP kernel
-            rc = get_mfma_group_lut(kmask, cfg->mode, &lut); if (rc) return rc;
+        if (!single_k) {                                                 // several k in the frame: try the matrix-core UEP kernel (bands grouped by k; any band subset)
+            rc = get_mfma_group_lut(km, cfg->mode, &lut); if (rc) return rc;
             uep = plan_enc_group(L, *cfg, m, fe, *lut, e, true);
         }
         if (mfma) {                                                      // matrix-core kernel: 64 or 32 blocks per band and tile

@@ -315,8 +315,9 @@ struct IlCursor {
         rowlen = min(a.il_w, take - rw);
     }
     __device__ __forceinline__ uint32_t get() const { return base + rw + (odd ? rowlen - 1u - c : c); }
-    __device__ __forceinline__ void next(const EncArgs& a) {
-        if (++c == rowlen) {
+    __device__ __forceinline__ void next(const EncArgs& a, const uint32_t step = 1u) {     // step 4: rows that are multiples of 4
+        c += step;
+        if (c >= rowlen) {
             c = 0; rw += a.il_w; odd ^= 1u;
             if (rw >= take) { base += a.il_A; take = min(a.il_A, a.n_sym - base); rw = 0; odd = 0; }
             rowlen = min(a.il_w, take - rw);
@@ -332,6 +333,43 @@ __device__ __forceinline__ uint32_t il_row_end(uint32_t u, const EncArgs& a) {  
     const uint32_t take = min(a.il_A, a.n_sym - base);
     const uint32_t r = fdiv(rem, a.div_w);
     return base + r * a.il_w + min(a.il_w, take - r * a.il_w);
+}
+
+// Row segment of position u: start, length, parity (odd rows are reversed)
+__device__ __forceinline__ void il_row(uint32_t u, const EncArgs& a, uint32_t& rl, uint32_t& rn, uint32_t& odd) {
+    const uint32_t chunk = fdiv(u, a.div_A), base = chunk * a.il_A, rem = u - base;
+    const uint32_t take = min(a.il_A, a.n_sym - base);
+    const uint32_t r = fdiv(rem, a.div_w);
+    rl = base + r * a.il_w; rn = min(a.il_w, take - r * a.il_w); odd = r & 1u;
+}
+// The pre-interleave symbols that land in the post-interleave tile [S0, S0 + TS): the map is an involution inside every row
+// segment, so whole rows of the tile come from themselves and only the tile's partial first / last row comes from the mirrored
+// piece of that row -- at most three runs of consecutive pre-interleave positions (ascending, adjacent ones merged), TS symbols
+// in all, whatever the row width.  Positions past the end of the stream map to themselves.
+struct IlRuns { uint32_t lo[3], hi[3], n; };
+__device__ __forceinline__ IlRuns il_runs(uint32_t S0, uint32_t TS, const EncArgs& a) {
+    IlRuns R; R.n = 0; R.lo[0] = R.lo[1] = R.lo[2] = 0; R.hi[0] = R.hi[1] = R.hi[2] = 0;
+    auto push = [&](uint32_t lo, uint32_t hi) {                                // (no dynamic indexing: the runs stay in registers)
+        if (lo >= hi) return;
+        if (R.n == 0u) { R.lo[0] = lo; R.hi[0] = hi; R.n = 1u; }
+        else if (R.n == 1u) { if (R.hi[0] == lo) R.hi[0] = hi; else { R.lo[1] = lo; R.hi[1] = hi; R.n = 2u; } }
+        else if (R.n == 2u) { if (R.hi[1] == lo) R.hi[1] = hi; else { R.lo[2] = lo; R.hi[2] = hi; R.n = 3u; } }
+        else if (R.hi[2] == lo) R.hi[2] = hi;
+    };
+    const uint32_t E = min(S0 + TS, a.n_sym);
+    if (S0 < E) {
+        uint32_t rl0, rn0, od0, rl1, rn1, od1;
+        il_row(S0, a, rl0, rn0, od0); il_row(E - 1u, a, rl1, rn1, od1);
+        if (rl0 == rl1) push(od0 ? rl0 + rn0 - (E - rl0) : S0, od0 ? rl0 + rn0 - (S0 - rl0) : E);
+        else {
+            const uint32_t he = rl0 + rn0;
+            push(od0 ? rl0 : S0, od0 ? he - (S0 - rl0) : he);
+            push(he, rl1);
+            push(od1 ? rl1 + rn1 - (E - rl1) : rl1, od1 ? rl1 + rn1 : E);
+        }
+    }
+    push(max(S0, a.n_sym), S0 + TS);
+    return R;
 }
 
 // Phase 2 for one lane: encode block m of band b and store its 26 bytes straight to the band's run in global memory.
@@ -691,20 +729,40 @@ __device__ __forceinline__ void rgb_px_to_comps(const uint32_t r8, const uint32_
     B = lds_u8(qt + Cb); R = lds_u8(qt + Cr);
 }
 
-template <int SC, int FE>
-__device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, uint32_t stage, uint64_t b0, uint32_t u_lo, uint32_t u_hi,
+// One run of consecutive pixel triples for phase 1: triples [t_base, t_end) in lane units of four (t_base a multiple of 4); triple t
+// reads its input at LDS address src0 + t * (18 | 9) (pixels | RGB)
+struct P1Run { uint32_t t_base, t_end, n_units, src0; };
+template <int FE>
+__device__ __forceinline__ P1Run p1_run(uint32_t u_lo, uint32_t u_hi, uint32_t stage) {    // symbols [u_lo, u_hi), their input staged at `stage` (see stage_input)
+    constexpr uint32_t GBf = FE == FE_PIXELS ? kGroupBytes : kGroupBytesRgb, TB = FE == FE_PIXELS ? 18u : 9u;
+    P1Run r; r.t_base = (u_lo / 13u) & ~3u; r.t_end = (u_hi + 12u) / 13u; r.n_units = (r.t_end - r.t_base + 3u) / 4u;
+    const uint64_t b0 = ((uint64_t)(r.t_base / 2u) * GBf) & ~15ull;                       // 16-aligned start of the first lane group (two triples each)
+    r.src0 = stage - (uint32_t)b0;                                                       // (wraps; src0 + t * TB does not)
+    (void)TB;
+    return r;
+}
+
+// IL: the symbols go to their post-interleave places in the tile [S0, S0 + TS) (what falls outside belongs to another tile);
+// else symbol u goes to sym_off + (u - S0).
+template <int SC, int FE, bool IL>
+__device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, const P1Run r0, const P1Run r1, const P1Run r2, uint32_t S0, uint32_t TS,
                                                       uint32_t lane, uint32_t wave, uint32_t nwv) {
-    const uint32_t S0 = u_lo;
-    const uint32_t t_base = (u_lo / 13u) & ~3u, t_end = (u_hi + 12u) / 13u;       // triples [t_base, t_end) cover them
+    constexpr uint32_t TB = FE == FE_PIXELS ? 18u : 9u;
     const uint32_t nw1 = min(a.p1_wpp, nwv);                                      // waves that convert (planner: just enough lanes)
     if (wave >= nw1) return;
-    for (uint32_t e0 = wave * 64u; t_base + 4u * e0 < t_end; e0 += nw1 * 64u) {
-        const uint32_t t = t_base + 4u * (e0 + lane);
+    const uint32_t n0 = r0.n_units, n01 = IL ? n0 + r1.n_units : n0, n_all = IL ? n01 + r2.n_units : n0;      // (separate values, not an array: selects, no private memory)
+    for (uint32_t e0 = wave * 64u; e0 < n_all; e0 += nw1 * 64u) {
+        const uint32_t e = e0 + lane;
+        const uint32_t ri = !IL ? 0u : e < n0 ? 0u : e < n01 ? 1u : 2u;            // (1-D: one run)
+        const uint32_t t_base = ri == 0u ? r0.t_base : ri == 1u ? r1.t_base : r2.t_base;
+        const uint32_t t_end = ri == 0u ? r0.t_end : ri == 1u ? r1.t_end : r2.t_end;
+        const uint32_t src0 = ri == 0u ? r0.src0 : ri == 1u ? r1.src0 : r2.src0;
+        const uint32_t t = t_base + 4u * (e - (ri == 0u ? 0u : ri == 1u ? n0 : n01));
         const bool live = t < t_end;
         u16x2 sA[13], sB[13];
         if constexpr (FE == FE_RGB) {
             // 12 pixels = 36 bytes = nine aligned dwords; pixel p = bytes 3p .. 3p + 2
-            const uint32_t src = stage + (uint32_t)((uint64_t)(live ? t : t_base) * 9u - b0);
+            const uint32_t src = src0 + (live ? t : t_base) * TB;
             uint32_t D[9];
 #pragma unroll
             for (uint32_t i = 0; i < 9; ++i) D[i] = lds_u32(src + 4u * i);
@@ -731,7 +789,7 @@ __device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, uint32_t
                 px3x2_to_sym13x8<SC>(c, pair ? sB : sA);
             }
         } else {
-        const uint32_t src = stage + (uint32_t)((uint64_t)(live ? t : t_base) * 18u - b0);   // 8-byte aligned
+        const uint32_t src = src0 + (live ? t : t_base) * TB;                             // 8-byte aligned
         uint32_t D[18];
 #pragma unroll
         for (uint32_t i = 0; i < 9; ++i) { const u32x2 v = *T3_LDS_PTR(u32x2, src + 8u * i); D[2 * i] = v.x; D[2 * i + 1] = v.y; }
@@ -776,11 +834,53 @@ __device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, uint32_t
         o[6] = __builtin_amdgcn_perm(E[0], O[5], LH);
         o[7] = __builtin_amdgcn_perm(E[2], E[1], HH);  o[8] = __builtin_amdgcn_perm(E[4], E[3], HH);  o[9] = __builtin_amdgcn_perm(X, E[5], HH);
         o[10] = __builtin_amdgcn_perm(O[1], O[0], HH); o[11] = __builtin_amdgcn_perm(O[3], O[2], HH); o[12] = __builtin_amdgcn_perm(O[5], O[4], HH);
-        if (live) {
-            const uint32_t dst = a.sym_off + 13u * t - S0;                        // dword aligned; may sit below sym_off (front slack)
+        if constexpr (!IL) {
+            if (live) {
+                const uint32_t dst = a.sym_off + 13u * t - S0;                    // dword aligned; may sit below sym_off (front slack)
 #pragma unroll
-            for (uint32_t j = 0; j < 6; ++j) *T3_LDS_WPTR(u32x2a4, dst + 8u * j) = u32x2a4{o[2 * j], o[2 * j + 1]};
-            *T3_LDS_WPTR(uint32_t, dst + 48u) = o[12];
+                for (uint32_t j = 0; j < 6; ++j) *T3_LDS_WPTR(u32x2a4, dst + 8u * j) = u32x2a4{o[2 * j], o[2 * j + 1]};
+                *T3_LDS_WPTR(uint32_t, dst + 48u) = o[12];
+            }
+        } else if (live) {
+            // 2-D boustrophedon folded into the stores (OLD:750-780): with rows, chunks and the tile start multiples of 4 an aligned
+            // dword of the stream stays an aligned dword -- in place in even rows, byte-reversed at the mirrored column in odd
+            // rows; any other geometry (and the stream's last, shorter row) goes symbol by symbol
+            const uint32_t u0 = 13u * t, lim = 13u * t_end;                       // u0: a multiple of 4; symbols from lim on were never converted
+            const bool rows4 = (a.il_w & 3u) == 0u && ((a.il_A & 3u) == 0u || a.il_A >= a.n_sym) && (S0 & 3u) == 0u && (TS & 3u) == 0u;
+            IlCursor cur;
+            if (u0 < a.n_sym) cur.init(u0, a);
+            if (rows4) {
+#pragma unroll
+                for (uint32_t j = 0; j < 13; ++j) {
+                    const uint32_t u = u0 + 4u * j;
+                    uint32_t v = u, val = o[j];
+                    bool whole = u + 4u <= lim;
+                    if (u < a.n_sym) {
+                        whole = whole && u + 4u <= a.n_sym && cur.rowlen == a.il_w;
+                        if (cur.odd) { v = cur.base + cur.rw + (a.il_w - 4u - cur.c); val = __builtin_bswap32(val); }
+                        cur.next(a, 4u);
+                    }
+                    if (whole) { if (v - S0 < TS) *T3_LDS_WPTR(uint32_t, a.sym_off + (v - S0)) = val; }
+                    else if (u < lim) {
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; ++i) {
+                            const uint32_t uu = u + i, vv = uu < a.n_sym ? il_perm(uu, a) : uu;
+                            if (uu < lim && vv - S0 < TS) *T3_LDS_WPTR(uint8_t, a.sym_off + (vv - S0)) = (uint8_t)(o[j] >> (8u * i));
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 13; ++j) {                              // (unrolled: o[] must stay in registers)
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) {
+                        const uint32_t u = u0 + 4u * j + i;
+                        uint32_t v = u;
+                        if (u < a.n_sym) { v = cur.get(); cur.next(a); }
+                        if (u < lim && v - S0 < TS) *T3_LDS_WPTR(uint8_t, a.sym_off + (v - S0)) = (uint8_t)(o[j] >> (8u * i));
+                    }
+                }
+            }
         }
     }
 }
@@ -810,7 +910,8 @@ __device__ __forceinline__ void barrier_input(uint32_t younger) {
 
 // RSEL = 26-k when every band of the launch shares one k (the common case: no dead code paths, fewer registers,
 // 640-thread bound so that two workgroups share a CU); RSEL = 0 handles mixed k with a wave-uniform switch.
-template <int FE, bool IL, int RSEL, bool BCN>
+// IL: 0 = 1-D; 1 = 2-D, whole rows + permutation pass (raw words: the row-by-row flow); 2 = 2-D, runs + permuting stores (wide rows)
+template <int FE, int IL, int RSEL, bool BCN>
 __device__ __forceinline__ void encode_body(const EncArgs& a) {
     constexpr uint32_t GS = fe_px(FE) ? kGroupSyms : kGroupSymsW;      // symbols per lane group
     constexpr uint32_t GBf = FE == FE_PIXELS ? kGroupBytes : FE == FE_RGB ? kGroupBytesRgb : kGroupBytesW;
@@ -880,17 +981,41 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     // first lane group whose input a tile starting at stream symbol S needs (pixels: the packed converter starts at a
     // multiple of 4 triples = 2 groups)
     auto first_group = [](uint32_t S) -> uint32_t { return fe_px(FE) ? ((S / 13u) & ~3u) / 2u : S / GS; };
-    // pre-interleave symbols [lo, hi) a tile starting at S needs: itself in 1-D; in 2-D the whole row segments it overlaps
-    // (the map stays inside a row segment, OLD:750-780) plus its own positions past the end of the stream (identity)
-    auto need_lo = [&](uint32_t S) -> uint32_t { return (IL && S < a.n_sym) ? il_row_start(S, a) : S; };
-    auto need_hi = [&](uint32_t S) -> uint32_t { return (IL && S < a.n_sym) ? max(il_row_end(min(S + TS, a.n_sym) - 1u, a), S + TS) : S + TS; };
-    // pipelined flow (input prefetch, packed converter): always in 1-D; in 2-D when the planner could afford it (il_async):
-    // phase 1 then leaves the symbols in PRE-interleave order and a permutation pass moves them, in post-interleave order,
-    // into the stage buffer the tile's input has just been consumed from
-    const bool fast = !IL || a.il_async != 0;
+    // pipelined flow (input prefetch, packed converter): always in 1-D; in 2-D for pixel / RGB input (il_async != 0):
+    //   il_async == 1 (rows up to 512 symbols): the tile's input covers the whole row segments it overlaps; phase 1 leaves the symbols in
+    //     PRE-interleave order and a permutation pass by all waves moves them, in post-interleave order, into the stage buffer the
+    //     tile's input has just been consumed from (measured: cheaper than permuting in the three converting waves' stores);
+    //   il_async == 2 (wider rows): the tile's pre-interleave symbols are up to three runs (il_runs) staged one behind the other and
+    //     phase 1 stores every symbol at its post-interleave place -- no row is staged whole, any width.
+    // (Raw words in 2-D keep the row-by-row flow below.)
+    const bool fast = !IL || a.il_async != 0;                                  // (a.il_async == IL for pixel / RGB input)
+    // the runs of a tile and where each one's input sits in a stage buffer: run i at kRunPitch-rounded offsets (an LDS-DMA piece is
+    // a whole KiB, so a run's last piece may reach up to 1008 bytes past its end)
+    struct TileIn { uint32_t lo[3], hi[3], off[3], n; };
+    auto tile_in = [&](uint32_t S) -> TileIn {
+        TileIn T; T.n = 1; T.lo[0] = S; T.hi[0] = S + TS; T.off[0] = 0; T.lo[1] = T.lo[2] = T.hi[1] = T.hi[2] = 0; T.off[1] = T.off[2] = 0;
+        if constexpr (IL == 1 && fe_px(FE)) {                                  // narrow rows: the whole row segments the tile overlaps, one run
+            if (S < a.n_sym) { T.lo[0] = il_row_start(S, a); T.hi[0] = max(il_row_end(min(S + TS, a.n_sym) - 1u, a), S + TS); }
+            return T;
+        }
+        if constexpr (IL == 2 && fe_px(FE)) {
+            const IlRuns R = il_runs(S, TS, a);
+            T.n = R.n; uint32_t off = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 3; ++i) {
+                T.lo[i] = R.lo[i]; T.hi[i] = R.hi[i]; T.off[i] = off;
+                const uint32_t bytes = (uint32_t)((uint64_t)((R.hi[i] + GS - 1u) / GS) * GBf - (((uint64_t)first_group(R.lo[i]) * GBf) & ~15ull));
+                if (i < R.n) off += (bytes + 1023u + 16u) & ~1023u;
+            }
+        }
+        return T;
+    };
+    auto stage_tile = [&](const TileIn& T, uint32_t stage, uint32_t w, uint32_t nw) {
+#pragma unroll
+        for (uint32_t i = 0; i < 3; ++i) if (i < T.n) stage_input<FE>(a, stage + T.off[i], first_group(T.lo[i]), (T.hi[i] + GS - 1u) / GS, lane, w, nw);
+    };
     if (fast) {                                                              // prologue: first tile's input
-        const uint32_t S = blockIdx.x * TS;
-        if (blockIdx.x < a.n_tiles) stage_input<FE>(a, a.stage_off, first_group(need_lo(S)), (need_hi(S) + GS - 1u) / GS, lane, wave, nwv);
+        if (blockIdx.x < a.n_tiles) stage_tile(tile_in(blockIdx.x * TS), a.stage_off, wave, nwv);
     }
     uint32_t younger = 0;                                                    // VMEM ops this wave issued after its last prefetch
     // Tiles are handed out dynamically: the three workgroups of a CU progress at different speeds (oldest wave first),
@@ -931,20 +1056,25 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             T3_STAMP(0);
             if (drawer) *(uint32_t*)(lds + 328) = cls + NC * (2u * wgc + atomicAdd(ctr, 1u));   // the tile after the next one (read after the barrier below)
 #ifndef T3_ABL_NO_PREFETCH
-            if (nxt < a.n_tiles && vw >= w0 && vw - w0 < n_pf)
-                stage_input<FE>(a, a.stage_off + (par ^ 1u) * a.stage_stride, first_group(need_lo(nxt * TS)), (need_hi(nxt * TS) + GS - 1u) / GS, lane, vw - w0, n_pf);
+            if (nxt < a.n_tiles && vw >= w0 && vw - w0 < n_pf) stage_tile(tile_in(nxt * TS), a.stage_off + (par ^ 1u) * a.stage_stride, vw - w0, n_pf);
 #endif
             T3_STAMP(4);
+            uint32_t u_lo = S0;
 #ifndef T3_ABL_NO_P1
-            const uint32_t u_lo = need_lo(S0), u_hi = need_hi(S0);
-            if constexpr (fe_px(FE)) convert_pixels_packed<(1 << SH), FE>(a, stage, ((uint64_t)first_group(u_lo) * GBf) & ~15ull, u_lo, u_hi, lane, vw, nwv);
-            else convert_groups<FE, false, SH>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, vw * 64u + lane, nthr);
+            if constexpr (fe_px(FE)) {
+                const TileIn T = tile_in(S0);
+                P1Run r0 = p1_run<FE>(T.lo[0], T.hi[0], stage + T.off[0]), r1 = p1_run<FE>(T.lo[1], T.hi[1], stage + T.off[1]), r2 = p1_run<FE>(T.lo[2], T.hi[2], stage + T.off[2]);
+                if (T.n < 1u) r0.n_units = 0; if (T.n < 2u) r1.n_units = 0; if (T.n < 3u) r2.n_units = 0;
+                u_lo = T.lo[0];
+                if constexpr (IL == 1) convert_pixels_packed<(1 << SH), FE, false>(a, r0, r1, r2, u_lo, TS, lane, vw, nwv);   // pre-interleave order; the pass below moves them
+                else convert_pixels_packed<(1 << SH), FE, IL == 2>(a, r0, r1, r2, S0, TS, lane, vw, nwv);
+            } else convert_groups<FE, false, SH>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, vw * 64u + lane, nthr);
 #endif
             T3_STAMP(5);                                                      // (diagnostic) this wave's conversion
             barrier_lds();                                                    // symbols complete
             T3_STAMP(1);
             nn = dyn ? __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + 328)) : nxt + gridDim.x;   // the tile after the next one
-            if constexpr (IL) {
+            if constexpr (IL == 1) {
                 // permutation pass: post-interleave position v of the tile <- pre-interleave symbol il_perm(v) (an involution);
                 // one lane = 4 consecutive positions = one dword of the image phase 2 reads
                 // Rows of the chunk grid map onto themselves, and with rows that are multiples of 4 symbols (tile edges and chunk sizes
@@ -1098,11 +1228,11 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 #ifndef T3_ENC_WAVES_PER_EU
 #define T3_ENC_WAVES_PER_EU 6   // <= 80 VGPRs: three 8-wave workgroups per CU
 #endif
-template <int FE, bool IL, int RSEL, bool BCN>
+template <int FE, int IL, int RSEL, bool BCN>
 __global__ __launch_bounds__(512, T3_ENC_WAVES_PER_EU) void encode_kernel_k(const EncArgs a) { encode_body<FE, IL, RSEL, BCN>(a); }
-template <int FE, bool IL, bool BCN>
+template <int FE, int IL, bool BCN>
 __global__ __launch_bounds__(512, T3_ENC_WAVES_PER_EU) void encode_kernel_uep(const EncArgs a) { encode_body<FE, IL, 1, BCN>(a); }   // UEP on the matrix cores
-template <int FE, bool IL>
+template <int FE, int IL>
 __global__ __launch_bounds__(1024) void encode_kernel_mixed(const EncArgs a) { encode_body<FE, IL, 0, false>(a); }
 
 #define T3_INST_KB(FE, IL, BCN) \
@@ -1110,7 +1240,7 @@ __global__ __launch_bounds__(1024) void encode_kernel_mixed(const EncArgs a) { e
     template __global__ void encode_kernel_k<FE, IL, 6, BCN>(const EncArgs); template __global__ void encode_kernel_k<FE, IL, 8, BCN>(const EncArgs); \
     template __global__ void encode_kernel_uep<FE, IL, BCN>(const EncArgs);
 #define T3_INST_K(FE, IL) T3_INST_KB(FE, IL, false) T3_INST_KB(FE, IL, true) template __global__ void encode_kernel_mixed<FE, IL>(const EncArgs);
-T3_INST_K(FE_PIXELS, false) T3_INST_K(FE_PIXELS, true) T3_INST_K(FE_WORDS, false) T3_INST_K(FE_WORDS, true) T3_INST_K(FE_RGB, false) T3_INST_K(FE_RGB, true)
+T3_INST_K(FE_PIXELS, 0) T3_INST_K(FE_PIXELS, 1) T3_INST_K(FE_PIXELS, 2) T3_INST_K(FE_WORDS, 0) T3_INST_K(FE_WORDS, 1) T3_INST_K(FE_RGB, 0) T3_INST_K(FE_RGB, 1) T3_INST_K(FE_RGB, 2)
 
 // ---------------------------------------------------------------------------------------------------------
 // beacon insertion pass (OLD:1118-1141): framed[q] = beacon symbol at slot `slot` of every period-th word, else
