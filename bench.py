@@ -401,7 +401,7 @@ def main():
     }
     if not args.encode_only:      # the decoder is the longer kernel of the step: same definition, SURVEY 8d decode bytes + 6 B/px
         dec_bytes = 9 * n_fenc + 6 * NPX
-        out["roofline_decode"] = {"kernel": "decode_fixed_kernel<r=6, to_pixels>" + (" (+ header read-back and failure-flag sync of the synchronous entry point)" if args.sync_decode else " (+ header check kernel; the index record's CRC kernel runs beside it)"),
+        out["roofline_decode"] = {"kernel": "decode_fixed_px_kernel<r=6, pixels>" + (" (+ header read-back and failure-flag sync of the synchronous entry point)" if args.sync_decode else " (+ header check kernel)"),
                                   "bound": "hbm", "achieved": round(dec_bytes / (dec_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(dec_bytes / (dec_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc("pmc_decode_latest.json"),
                                   "algorithmic_bytes_per_launch": dec_bytes, "launch_ms": round(dec_avg, 4)}

@@ -64,5 +64,5 @@ python3 profiles/other_configs.py > $out/other_configs.json 2>> $out/side.err
 python3 profiles/decode_configs.py > $out/decode_configs.json 2>> $out/side.err
 python3 profiles/rgb_time.py > $out/rgb_time.json 2>> $out/side.err
 python3 profiles/copy_ceiling.py > $out/copy_ceiling.json 2>> $out/side.err
-for m in clean errors; do python3 profiles/dec_loop.py $m 50 300 c2 2>/dev/null | tail -1; done > $out/dec_loop.txt; cat $out/dec_loop.txt
+for m in clean errors; do for c in c2 beacon c3 words; do python3 profiles/dec_loop.py $m 50 300 $c 2>/dev/null | tail -1; done; done > $out/dec_loop.txt; cat $out/dec_loop.txt
 echo done
