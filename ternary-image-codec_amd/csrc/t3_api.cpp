@@ -161,6 +161,7 @@ uint32_t p1_waves_per_parity(uint32_t TS) {
 // dealt linearly into sets of 32; eight waves take two sets each
 bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, int fe, const LutImage& lut, EncLaunch& out, bool grp = false) {
     EncArgs& a = out.a; memset(&a, 0, sizeof a);
+    const bool il2d = L.interleave2d && cfg.tile_w > 1;                  // rows of one symbol: the boustrophedon map is the identity (and the kernels' row divisions assume >= 2)
     const uint32_t GS = fe_px(fe) ? kGroupSyms : kGroupSymsW, GB = fe == FE_PIXELS ? kGroupBytes : fe == FE_RGB ? kGroupBytesRgb : kGroupBytesW;
     uint64_t Lk = 2;
     for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) Lk = Lk / gcd64(Lk, L.band_k[b]) * L.band_k[b];
@@ -169,7 +170,8 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     // w - 1 extra symbols each side) and a permutation pass follows phase 1 (il_async 1); wider rows -- the tile's pre-interleave symbols
     // are up to three runs, staged one behind the other at 1-KiB pitches, and phase 1 stores each symbol at its post-interleave place
     // (il_async 2; t3_kernels.hip, il_runs)
-    const uint32_t il_async = !(L.interleave2d && fe_px(fe)) ? 0u : cfg.tile_w <= 512 ? 1u : 2u;
+    static const uint32_t force_il = getenv("T3HIP_FORCE_IL") ? (uint32_t)atoi(getenv("T3HIP_FORCE_IL")) : 0u;   // measurement knob: 1 / 2 = that flow for every row width it can take
+    const uint32_t il_async = !(il2d && fe_px(fe)) ? 0u : force_il == 2u ? 2u : (cfg.tile_w <= 512 ? 1u : 2u);
     const uint32_t il_extra = il_async == 1u ? 2u * cfg.tile_w : 0u;
     const uint32_t il_stage = il_async == 2u ? 2u * (1024u + 4u * GB + 32u) : 0u;   // two more runs: their rounding and pitch
     const uint32_t hdr = grp ? (uint32_t)kLdsHdrUep : (uint32_t)kLdsHdr;
@@ -199,7 +201,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
             }
             if (waves > (pass == 0 ? 8u : (uint32_t)kMaxWaves)) break;   // pass 0: 512-thread workgroups, three per CU
             const uint32_t groups = (uint32_t)((9 * Lq + il_extra) / GS) + 8, stage = groups * GB + 1024 + 32 + il_stage;   // +1 KiB: LDS-DMA pieces are whole
-            const uint32_t total = hdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq) + il_extra) + kSymBack + ((L.interleave2d && !il_async) ? 1u : 2u) * round16(stage) + (fe == FE_RGB ? 256u : 0u);
+            const uint32_t total = hdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq) + il_extra) + kSymBack + ((il2d && !il_async) ? 1u : 2u) * round16(stage) + (fe == FE_RGB ? 256u : 0u);
             if (total > budget) break;
             // wave-instructions per stream symbol: phase 2 costs ~180 per wave, phase 1 (pixels) ~120 per wave-iteration
             const uint32_t wpp = p1_waves_per_parity((uint32_t)(9 * Lq) + il_extra + (il_async == 2u ? 312u : 0u));   // (three runs: up to six lane units of rounding)
@@ -233,14 +235,14 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     a.n_items = nw; a.n_tiles = n_tiles;
     { uint32_t acc = 0; for (int b = 0; b < 9; ++b) { a.band_first[b] = acc; acc += a.band_nb_tile[b]; } a.band_first[9] = acc; }
     a.stage_stride = round16(a.stage_groups * GB + 1024 + 32 + il_stage);
-    a.lds_bytes = a.stage_off + ((L.interleave2d && !il_async) ? 1u : 2u) * a.stage_stride;   // pipelined flow: two stage buffers (the next tile streams in early)
+    a.lds_bytes = a.stage_off + ((il2d && !il_async) ? 1u : 2u) * a.stage_stride;   // pipelined flow: two stage buffers (the next tile streams in early)
     if (fe == FE_RGB) { a.qt_off = a.lds_bytes; a.lds_bytes += 256u; }                            // chroma quantiser table of the fused bridge
     a.il_async = il_async;
     a.n_sym = (uint32_t)L.n_sym;
     const ScrCycle sc = scrambler_cycle(cfg.seed_a, cfg.seed_b, cfg.seed_s0);
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
     mfma_scrambler_table(L.band_k[0], sc, a.scr);
-    a.il_on = L.interleave2d;
+    a.il_on = il2d;
     if (a.il_on) {
         const uint64_t A = (uint64_t)cfg.tile_w * cfg.tile_h;
         a.il_w = cfg.tile_w; a.il_A = (uint32_t)std::min<uint64_t>(A, std::max<uint64_t>(L.n_sym, 1));

@@ -27,6 +27,10 @@ __device__ __forceinline__ uint32_t lds_u8(uint32_t a)  { return *T3_LDS_PTR(uin
 __device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *T3_LDS_PTR(uint32_t, a); }
 
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, const DevDiv& d) { return d.d <= 1 ? n : (__umulhi(n, d.mul) >> d.sh); }
+// ... for divisors known to be >= 2 (2-D geometry: the host takes rows of one symbol, where the map is the identity, as 1-D).  No test on d:
+// hoisted out of the tile loop that test lived in a register pair the kernels did not have, was parked in a VGPR, spilled, and its reload
+// (scratch_load + s_waitcnt vmcnt(0)) drained the next tile's prefetch in the middle of phase 1.
+__device__ __forceinline__ uint32_t fdiv2(uint32_t n, const DevDiv& d) { return __umulhi(n, d.mul) >> d.sh; }
 
 // ---------------------------------------------------------------------------------------------------------
 // small-integer division by powers of three with full-rate 24-bit multiplies (ranges checked in tests/test_host_logic.py)
@@ -299,9 +303,9 @@ __device__ __forceinline__ Blk26 encode_block(uint32_t sym_addr, uint32_t lut_rt
 
 // 2-D boustrophedon position map (an involution inside each row segment; OLD:750-780)
 __device__ __forceinline__ uint32_t il_perm(uint32_t u, const EncArgs& a) {
-    const uint32_t chunk = fdiv(u, a.div_A), base = chunk * a.il_A, rem = u - base;
+    const uint32_t chunk = fdiv2(u, a.div_A), base = chunk * a.il_A, rem = u - base;
     const uint32_t take = min(a.il_A, a.n_sym - base);
-    const uint32_t r = fdiv(rem, a.div_w), c = rem - r * a.il_w;
+    const uint32_t r = fdiv2(rem, a.div_w), c = rem - r * a.il_w;
     const uint32_t rowlen = min(a.il_w, take - r * a.il_w);
     return base + r * a.il_w + ((r & 1u) ? rowlen - 1u - c : c);
 }
@@ -309,9 +313,9 @@ __device__ __forceinline__ uint32_t il_perm(uint32_t u, const EncArgs& a) {
 struct IlCursor {
     uint32_t base, take, rw, c, rowlen, odd;                 // chunk start, chunk size, row start in the chunk, column, row length, row parity
     __device__ __forceinline__ void init(uint32_t u, const EncArgs& a) {
-        const uint32_t chunk = fdiv(u, a.div_A); base = chunk * a.il_A;
+        const uint32_t chunk = fdiv2(u, a.div_A); base = chunk * a.il_A;
         const uint32_t rem = u - base; take = min(a.il_A, a.n_sym - base);
-        const uint32_t r = fdiv(rem, a.div_w); rw = r * a.il_w; c = rem - rw; odd = r & 1u;
+        const uint32_t r = fdiv2(rem, a.div_w); rw = r * a.il_w; c = rem - rw; odd = r & 1u;
         rowlen = min(a.il_w, take - rw);
     }
     __device__ __forceinline__ uint32_t get() const { return base + rw + (odd ? rowlen - 1u - c : c); }
@@ -325,21 +329,21 @@ struct IlCursor {
     }
 };
 __device__ __forceinline__ uint32_t il_row_start(uint32_t u, const EncArgs& a) {
-    const uint32_t chunk = fdiv(u, a.div_A), base = chunk * a.il_A, rem = u - base;
-    return base + fdiv(rem, a.div_w) * a.il_w;
+    const uint32_t chunk = fdiv2(u, a.div_A), base = chunk * a.il_A, rem = u - base;
+    return base + fdiv2(rem, a.div_w) * a.il_w;
 }
 __device__ __forceinline__ uint32_t il_row_end(uint32_t u, const EncArgs& a) {   // one past the last symbol of u's row segment
-    const uint32_t chunk = fdiv(u, a.div_A), base = chunk * a.il_A, rem = u - base;
+    const uint32_t chunk = fdiv2(u, a.div_A), base = chunk * a.il_A, rem = u - base;
     const uint32_t take = min(a.il_A, a.n_sym - base);
-    const uint32_t r = fdiv(rem, a.div_w);
+    const uint32_t r = fdiv2(rem, a.div_w);
     return base + r * a.il_w + min(a.il_w, take - r * a.il_w);
 }
 
 // Row segment of position u: start, length, parity (odd rows are reversed)
 __device__ __forceinline__ void il_row(uint32_t u, const EncArgs& a, uint32_t& rl, uint32_t& rn, uint32_t& odd) {
-    const uint32_t chunk = fdiv(u, a.div_A), base = chunk * a.il_A, rem = u - base;
+    const uint32_t chunk = fdiv2(u, a.div_A), base = chunk * a.il_A, rem = u - base;
     const uint32_t take = min(a.il_A, a.n_sym - base);
-    const uint32_t r = fdiv(rem, a.div_w);
+    const uint32_t r = fdiv2(rem, a.div_w);
     rl = base + r * a.il_w; rn = min(a.il_w, take - r * a.il_w); odd = r & 1u;
 }
 // The pre-interleave symbols that land in the post-interleave tile [S0, S0 + TS): the map is an involution inside every row
@@ -519,7 +523,7 @@ __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t symb,
             // have no run before it that holds that beacon): this lane writes it.  bcn_pb >= 17: one beacon per run at most.
             const uint32_t g0 = (uint32_t)s.goff + 10u * h;                       // body symbols are 31-bit (plan_layout)
             uint32_t nb0 = 0, c = a.bcn_slot - g0;
-            if (g0 >= a.bcn_slot) { const uint32_t u = g0 - a.bcn_slot, j = fdiv(u, a.bcn_div); nb0 = j + 1u; c = a.bcn_pb - (u - j * a.bcn_pb); }
+            if (g0 >= a.bcn_slot) { const uint32_t u = g0 - a.bcn_slot, j = fdiv2(u, a.bcn_div); nb0 = j + 1u; c = a.bcn_pb - (u - j * a.bcn_pb); }
             const bool inside = c < 16u, pre = nb0 != 0u && c == a.bcn_pb;
             const uint32_t dc = inside ? c >> 2 : 4u, bc = c & 3u;
             const uint32_t Ed = dc == 0u ? E.v[0] : dc == 1u ? E.v[1] : dc == 2u ? E.v[2] : E.v[3];
@@ -988,7 +992,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     //   il_async == 2 (wider rows): the tile's pre-interleave symbols are up to three runs (il_runs) staged one behind the other and
     //     phase 1 stores every symbol at its post-interleave place -- no row is staged whole, any width.
     // (Raw words in 2-D keep the row-by-row flow below.)
-    const bool fast = !IL || a.il_async != 0;                                  // (a.il_async == IL for pixel / RGB input)
+    constexpr bool fast = !IL || fe_px(FE);                                    // (the host sets a.il_async == IL for pixel / RGB input, 0 for raw words)
     // the runs of a tile and where each one's input sits in a stage buffer: run i at kRunPitch-rounded offsets (an LDS-DMA piece is
     // a whole KiB, so a run's last piece may reach up to 1008 bytes past its end)
     struct TileIn { uint32_t lo[3], hi[3], off[3], n; };
@@ -1014,7 +1018,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 #pragma unroll
         for (uint32_t i = 0; i < 3; ++i) if (i < T.n) stage_input<FE>(a, stage + T.off[i], first_group(T.lo[i]), (T.hi[i] + GS - 1u) / GS, lane, w, nw);
     };
-    if (fast) {                                                              // prologue: first tile's input
+    if constexpr (fast) {                                                    // prologue: first tile's input
         if (blockIdx.x < a.n_tiles) stage_tile(tile_in(blockIdx.x * TS), a.stage_off, wave, nwv);
     }
     uint32_t younger = 0;                                                    // VMEM ops this wave issued after its last prefetch
@@ -1051,7 +1055,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
         const uint32_t stage = a.stage_off + (fast ? par * a.stage_stride : 0u);
         uint32_t symb = a.sym_off;                                            // where phase 2 finds the tile's symbols
         // ---------------- phase 1: input -> stream-ordered symbols in LDS ----------------
-        if (fast) {
+        if constexpr (fast) {
             barrier_input(younger);                                           // this tile's input has landed, everyone left phase 2
             T3_STAMP(0);
             if (drawer) *(uint32_t*)(lds + 328) = cls + NC * (2u * wgc + atomicAdd(ctr, 1u));   // the tile after the next one (read after the barrier below)
@@ -1087,8 +1091,8 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
                     uint32_t w4 = 0;
                     bool done = false;
                     if (rows4 && v + 4u <= a.n_sym) {
-                        const uint32_t chunk = fdiv(v, a.div_A), base = chunk * a.il_A, rem = v - base, take = min(a.il_A, a.n_sym - base);
-                        const uint32_t r = fdiv(rem, a.div_w), rw = r * a.il_w, c = rem - rw, rowlen = min(a.il_w, take - rw);
+                        const uint32_t chunk = fdiv2(v, a.div_A), base = chunk * a.il_A, rem = v - base, take = min(a.il_A, a.n_sym - base);
+                        const uint32_t r = fdiv2(rem, a.div_w), rw = r * a.il_w, c = rem - rw, rowlen = min(a.il_w, take - rw);
                         if (!(r & 1u)) { w4 = lds_u32(a.sym_off + (v - u_lo)); done = true; }
                         else if (rowlen == a.il_w) { w4 = __builtin_bswap32(lds_u32(a.sym_off + (base + rw + (a.il_w - 4u - c) - u_lo))); done = true; }
                     }
@@ -1111,8 +1115,8 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
                     for (uint32_t q = tid; g0 + 16u * q < S0 + TS; q += nthr) {
                         const uint32_t v = g0 + 16u * q;
                         if (v >= S0 && v + 16u <= S0 + TS && v + 16u <= a.n_sym) {
-                            const uint32_t chunk = fdiv(v, a.div_A), base = chunk * a.il_A, rem = v - base, take = min(a.il_A, a.n_sym - base);
-                            const uint32_t r = fdiv(rem, a.div_w), rw = r * a.il_w, c = rem - rw, rowlen = min(a.il_w, take - rw);
+                            const uint32_t chunk = fdiv2(v, a.div_A), base = chunk * a.il_A, rem = v - base, take = min(a.il_A, a.n_sym - base);
+                            const uint32_t r = fdiv2(rem, a.div_w), rw = r * a.il_w, c = rem - rw, rowlen = min(a.il_w, take - rw);
                             if (!(r & 1u) || rowlen == a.il_w) {
                                 const uint32_t src = (r & 1u) ? base + rw + (a.il_w - 16u - c) : v;
                                 const u32x4 x = *T3_LDS_PTR(u32x4, a.sym_off + (src - u_lo));           // 16-byte aligned: rows start at multiples of 16 from u_lo

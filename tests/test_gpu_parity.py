@@ -27,6 +27,7 @@ CFGS = {
     "p5_beacon_slot9": dict(profile=4, uep=1, tile=(3, 4), beacon=(5, 9, 1)),
     "p5_wide_tile": dict(profile=4, uep=2, tile=(5000, 3)),
     "p5_wide16_tile": dict(profile=4, uep=1, tile=(4112, 7)),
+    "p5_one_symbol_rows": dict(profile=4, uep=2, tile=(1, 9)),
     "p3_seed_fixedpoint": dict(profile=2, uep=2, seed=(0, 2, 1)),
     "p3_seed_period2": dict(profile=2, uep=2, seed=(2, 0, 1)),
 }
