@@ -530,9 +530,24 @@ int t3hip_inject_errors_dev(void* d_words, uint64_t first_sym, uint64_t n_blocks
     HIPCHK(hipGetLastError()); return T3_OK;
 }
 
+// the CRC's leading 0xFFFFFFFF carried through n zero bytes (bitwise, 8 n steps would be too slow: square-and-multiply on the operator)
+static uint32_t crc_lead(uint64_t n_bytes) {
+    uint32_t x = 0xFFFFFFFFu;
+    uint32_t op[32], sq[32];                                          // operator "append 2^j zero bytes" as 32 columns; start with one zero byte
+    for (int b = 0; b < 32; ++b) { uint32_t v = 1u << b; for (int i = 0; i < 8; ++i) v = (v & 1u) ? (0xEDB88320u ^ (v >> 1)) : (v >> 1); op[b] = v; }
+    auto apply = [](const uint32_t* m, uint32_t v) { uint32_t r = 0; for (int b = 0; b < 32; ++b) if (v >> b & 1u) r ^= m[b]; return r; };
+    for (uint64_t n = n_bytes; n; n >>= 1) {
+        if (n & 1u) x = apply(op, x);
+        for (int b = 0; b < 32; ++b) sq[b] = apply(op, op[b]);
+        memcpy(op, sq, sizeof op);
+    }
+    return x;
+}
+
 // CRC + symbol-sum accumulation of a payload into acc[0] / acc[1] (zeroed here): whole 2 KiB rounds on the matrix cores
 // when the buffer is 16-byte aligned, the rest (or everything) through the table kernel
-static int launch_crc(const uint8_t* d_data, uint64_t n_bytes, uint32_t* acc, hipStream_t s) {
+// tail_off != null: a rest shorter than 2 KiB behind the matrix-core rounds is left to the caller's record kernel (*tail_off = where it starts)
+static int launch_crc(const uint8_t* d_data, uint64_t n_bytes, uint32_t* acc, hipStream_t s, uint64_t* tail_off = nullptr) {
     HIPCHK(hipMemsetAsync(acc, 0, 8, s));
     uint64_t done = 0;
     static const int rpw_env = [] { const char* e = getenv("T3HIP_CRC_ROUNDS_PER_WAVE"); return e ? atoi(e) : 0; }();
@@ -550,6 +565,7 @@ static int launch_crc(const uint8_t* d_data, uint64_t n_bytes, uint32_t* acc, hi
         hipLaunchKernelGGL(crc_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, m); HIPCHK(hipGetLastError());
         done = (uint64_t)m.n_rounds << 11;
     }
+    if (tail_off) { *tail_off = n_bytes; if (done && n_bytes - done < 2048) { *tail_off = done; return T3_OK; } }
     if (done < n_bytes) {
         CrcArgs c; memset(&c, 0, sizeof c);
         c.data = d_data + done; c.n_bytes = n_bytes - done; c.chunk_bytes = 2304;      // 256 words per lane
@@ -566,11 +582,11 @@ int t3hip_frame_record_dev(const void* d_words, uint64_t n_words, uint64_t frame
     if (!api_ready()) return T3_E_NODEVICE;
     if (!cfg || !d_rec || (n_words && !d_words) || !d_scratch || scratch_bytes < 8) return T3_E_ARG;
     hipStream_t s = (hipStream_t)stream;
-    CrcArgs c; memset(&c, 0, sizeof c);
-    c.data = (const uint8_t*)d_words; c.n_bytes = 9 * n_words;
-    c.chunk_crc = (uint32_t*)d_scratch; c.sym_sum = (uint32_t*)d_scratch + 1; c.zpow = d_zpow;
-    { const int rc = launch_crc(c.data, c.n_bytes, (uint32_t*)d_scratch, s); if (rc) return rc; }
-    hipLaunchKernelGGL(frame_record_kernel, dim3(1), dim3(64), 0, s, c, (const uint8_t*)d_words, n_words, frame_idx, (uint32_t)cfg->profile, (uint32_t)cfg->mode, (void*)d_rec);
+    const uint64_t n_bytes = 9 * n_words; uint64_t tail_off = n_bytes;
+    { const int rc = launch_crc((const uint8_t*)d_words, n_bytes, (uint32_t*)d_scratch, s, &tail_off); if (rc) return rc; }
+    hipLaunchKernelGGL(frame_record_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*)d_scratch, crc_lead(n_bytes),
+                       tail_off < n_bytes ? (const uint8_t*)d_words + tail_off : (const uint8_t*)nullptr, (uint32_t)(n_bytes - tail_off), (const uint32_t*)d_zpow,
+                       (const uint8_t*)d_words, n_words, frame_idx, (uint32_t)cfg->profile, (uint32_t)cfg->mode, (void*)d_rec);
     HIPCHK(hipGetLastError()); return T3_OK;
 }
 
@@ -586,18 +602,7 @@ int t3hip_crc32_dev(const void* d_data, uint64_t n_bytes, uint32_t* crc_out, voi
     HIPCHK(hipStreamSynchronize(s));
     // the kernel leaves the xor of the chunk remainders moved to the end of the stream; the leading 0xFFFFFFFF travels
     // through n_bytes zero bytes on the host (bitwise, 8 n steps would be too slow: square-and-multiply on the operator)
-    uint32_t x = 0xFFFFFFFFu;
-    {
-        // operator "append 2^j zero bytes" as 32 columns; start with one zero byte
-        uint32_t op[32], sq[32];
-        for (int b = 0; b < 32; ++b) { uint32_t v = 1u << b; for (int i = 0; i < 8; ++i) v = (v & 1u) ? (0xEDB88320u ^ (v >> 1)) : (v >> 1); op[b] = v; }
-        auto apply = [](const uint32_t* m, uint32_t v) { uint32_t r = 0; for (int b = 0; b < 32; ++b) if (v >> b & 1u) r ^= m[b]; return r; };
-        for (uint64_t n = n_bytes; n; n >>= 1) {
-            if (n & 1u) x = apply(op, x);
-            for (int b = 0; b < 32; ++b) sq[b] = apply(op, op[b]);
-            memcpy(op, sq, sizeof op);
-        }
-    }
+    const uint32_t x = crc_lead(n_bytes);
     *crc_out = (x ^ acc) ^ 0xFFFFFFFFu;
     return T3_OK;
 }

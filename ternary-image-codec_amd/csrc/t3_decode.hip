@@ -225,17 +225,38 @@ __global__ void hdr_compare_kernel(const uint8_t* in, const HdrExpect expect, ui
     if (threadIdx.x == 0) { verdict[0] = diff ? 1u : 0u; verdict[1] = 0u; }
 }
 
-__global__ void frame_record_kernel(const CrcArgs a, const uint8_t* words, uint64_t n_words, uint64_t frame_idx, uint32_t profile, uint32_t mode, void* recv) {
+// One wave.  acc[0] / acc[1]: XOR of the chunk remainders moved to the end of the stream / symbol sum, as the CRC kernels left them;
+// lead = the leading 0xFFFFFFFF carried through n_bytes zero bytes (host: square-and-multiply on the operator -- on the device that is a
+// chain of dependent global loads, 9 us); tail: the last tail_len < 2048 bytes of the stream that no matrix-core round covered (null: none).
+// The tail is taken right-aligned on a grid of 64 pieces of 32 bytes (leading zeros do not move a zero register), bit-serially per lane,
+// and the pieces are joined by a butterfly of "append 32 * 2^l zero bytes" operators -- it sits at the end of the stream, so its
+// remainder needs no further shift.
+__global__ __launch_bounds__(64) void frame_record_kernel(const uint32_t* acc, uint32_t lead, const uint8_t* tail, uint32_t tail_len, const uint32_t* zpow,
+                                                          const uint8_t* words, uint64_t n_words, uint64_t frame_idx, uint32_t profile, uint32_t mode, void* recv) {
     t3_frame_record* rec = (t3_frame_record*)recv;
-    if (threadIdx.x == 0) {
-        // x = Z_total(0xFFFFFFFF) ^ acc, then the final inversion
-        const uint32_t x = crc_shift(a.zpow, 0xFFFFFFFFu, a.n_bytes);
+    const uint32_t lane = threadIdx.x;
+    uint32_t r = 0, sum = 0;
+    if (tail && tail_len) {
+        const int32_t lo = (int32_t)tail_len - 32 * (int32_t)(64u - lane);
+        for (int32_t i = lo < 0 ? 0 : lo; i < lo + 32; ++i) {
+            const uint32_t v = tail[i]; sum += v; r ^= v;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r = (r & 1u) ? (0xEDB88320u ^ (r >> 1)) : (r >> 1);
+        }
+#pragma unroll
+        for (uint32_t l = 0; l < 6; ++l) {
+            const uint32_t other = __shfl_xor(r, 1 << l), up = (lane >> l) & 1u;
+            r = gf2_apply(zpow + 32u * (5u + l), up ? other : r) ^ (up ? r : other);
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    }
+    if (lane == 0) {
         rec->frame_idx = frame_idx; rec->n_words = n_words; rec->byte_offset = 0;
-        rec->crc32 = (x ^ *a.chunk_crc) ^ 0xFFFFFFFFu; rec->sym_sum = *a.sym_sum;
+        rec->crc32 = (lead ^ acc[0] ^ r) ^ 0xFFFFFFFFu; rec->sym_sum = acc[1] + sum;      // final inversion
         rec->profile = (uint8_t)profile; rec->mode = (uint8_t)mode;
         for (int i = 0; i < 8; ++i) rec->pad_[i] = 0;
     }
-    if (threadIdx.x < 54) rec->header_syms[threadIdx.x] = threadIdx.x < 9 * n_words ? words[threadIdx.x] : 0;
+    if (lane < 54) rec->header_syms[lane] = lane < 9 * n_words ? words[lane] : 0;
 }
 
 }  // namespace t3

@@ -339,7 +339,8 @@ def test_error_injector_matches_host(gpu, orc):
 def test_frame_record(gpu, orc):
     import torch
     rng = np.random.default_rng(4)
-    for n in (0, 1, 6, 255, 256, 257, 100000):
+    # the last sizes go through the matrix-core rounds; their rests (9 n mod 2048 = 4 .. 2047) are taken by the record kernel itself
+    for n in (0, 1, 6, 255, 256, 257, 100000) + tuple(range(14564, 14564 + 228, 19)) + (14564 + 227, 16384, 20766726 // 64):
         w = rng.integers(0, 27, size=(n, 9), dtype=np.uint8)
         d = torch.from_numpy(w).cuda() if n else torch.zeros(16, dtype=torch.uint8, device="cuda")
         rec = torch.zeros(gpu.FRAME_RECORD_BYTES, dtype=torch.uint8, device="cuda"); scr = torch.zeros(64, dtype=torch.uint8, device="cuda")
