@@ -46,6 +46,7 @@ __device__ __forceinline__ v4i parity_bytes(const v16i& acc) {
     return fb;
 }
 
+#define T3_CRC_LD(p) (*(const uint4*)(p))      // (non-temporal loads measured slower here: 0.074 vs 0.070 ms per 187 MB frame)
 __global__ __launch_bounds__(256) void crc_mfma_kernel(const CrcMArgs a) {
     __shared__ uint32_t red[2 * 16];
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, kh = lane >> 5, wave = threadIdx.x >> 6;
@@ -62,11 +63,11 @@ __global__ __launch_bounds__(256) void crc_mfma_kernel(const CrcMArgs a) {
     v4i fb = {0, 0, 0, 0};
     uint32_t sum = 0;
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
-    if (r0 < r1) { q0 = *(const uint4*)p; q1 = *(const uint4*)(p + 16); }
+    if (r0 < r1) { q0 = T3_CRC_LD(p); q1 = T3_CRC_LD(p + 16); }
     for (uint64_t r = r0; r < r1; ++r) {
         const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
         p += 2048;
-        if (r + 1 < r1) { q0 = *(const uint4*)p; q1 = *(const uint4*)(p + 16); }          // next round's bytes, in flight under this round's arithmetic
+        if (r + 1 < r1) { q0 = T3_CRC_LD(p); q1 = T3_CRC_LD(p + 16); }          // next round's bytes, in flight under this round's arithmetic
 #pragma unroll
         for (int i = 0; i < 8; ++i) sum = __builtin_amdgcn_sad_u8(w[i], 0u, sum);
         v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[16], fb, zero, 0, 0, 0);     // running remainder, 2048 bytes further on

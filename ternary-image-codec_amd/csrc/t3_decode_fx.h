@@ -134,7 +134,7 @@ __device__ __forceinline__ void fx_block(const FxCtx& cx, const Row rw, const ui
         const uint32_t* p = (const uint32_t*)((uintptr_t)g & ~(uintptr_t)3);
         uint32_t dw[7];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) dw[i] = p[i];
+        for (int i = 0; i < 7; ++i) dw[i] = __builtin_nontemporal_load(p + i);     // the coded stream is read once (as in t3_decode_fused.hip)
 #pragma unroll
         for (int i = 0; i < 6; ++i) w[i] = __builtin_amdgcn_alignbit(dw[i + 1], dw[i], sh);
         w[6] = dw[6] >> sh;

@@ -566,6 +566,9 @@ __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t symb,
 // byte b0 + x with b0 = 16-aligned start of group g_lo.  Whole 1-KiB pieces inside the real data go by LDS-DMA
 // (global_load_lds_dwordx4: no VGPR round trip, completes behind vmcnt, so the next tile's input streams in under
 // this tile's compute); pieces that touch the end of the data are synthesised (pad pixel OLD:730, then zero trits).
+#ifndef T3_DMA_AUX
+#define T3_DMA_AUX 3   // cache policy of the input LDS-DMA: sc0 | nt (the input is read once; measured 2-3 % over the default policy, profiles/r02/notes.md)
+#endif
 template <int FE>
 __device__ __forceinline__ void stage_input(const EncArgs& a, uint32_t stage, uint32_t g_lo, uint32_t g_hi, uint32_t lane, uint32_t wave, uint32_t nwv) {
     constexpr uint32_t GB = FE == FE_PIXELS ? kGroupBytes : FE == FE_RGB ? kGroupBytesRgb : kGroupBytesW, UB = FE == FE_PIXELS ? 6u : FE == FE_RGB ? 3u : 9u;
@@ -575,7 +578,7 @@ __device__ __forceinline__ void stage_input(const EncArgs& a, uint32_t stage, ui
         const uint64_t o = b0 + 16ull * (c0 + lane);
         if (b0 + 16ull * (c0 + 64u) <= real) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t*)(a.in + o),
-                                             (__attribute__((address_space(3))) uint32_t*)(lds + stage + 16u * c0), 16, 0, 0);
+                                             (__attribute__((address_space(3))) uint32_t*)(lds + stage + 16u * c0), 16, 0, T3_DMA_AUX);
         } else if (c0 + lane < n_chunks) {
             uint32_t w[4] = {0, 0, 0, 0};
             if (o + 16u <= real) { const uint4 v = *(const uint4*)(a.in + o); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
