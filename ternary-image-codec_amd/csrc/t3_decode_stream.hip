@@ -124,26 +124,44 @@ template <bool TO_PIXELS>
 __global__ __launch_bounds__(512, 2) void emit_stream_kernel(const EmitStArgs a) {
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t units_step = TO_PIXELS ? (a.span / 13u) * 3u : (a.span / 26u) * 3u;
+    // The de-interleave map is an involution inside every row segment (odd rows reversed, OLD:782-813): a step's pre-interleave symbols
+    // [U0, U1) are gathered straight from their mirrored places in the corrected stream, whatever the row width -- nothing but the step
+    // itself is read or staged.  The next step's granules (four per thread) are requested into registers before this step's conversion and
+    // written to LDS after it, so the loads' latency lies under the conversion and its stores.
+    constexpr uint32_t G = 4;                                                       // 16-byte granules per thread and step (span <= 16 * G * 512)
+    const bool regs = (!a.il_on || a.il_fast) && a.span <= 16u * G * nthr;
+    uint4 R[G]; uint32_t have = 0;
+    auto fetch = [&](uint32_t st) {
+        have = 0;
+        const uint32_t U0 = st * a.span, U1 = (uint32_t)min((uint64_t)U0 + a.span, (uint64_t)a.n_sym);
+#pragma unroll
+        for (uint32_t k = 0; k < G; ++k) {
+            const uint32_t v = U0 + 16u * (tid + k * nthr);
+            if (v >= U1) continue;
+            if (!a.il_on) { R[k] = *(const uint4*)(a.ystream + v); have |= 1u << k; continue; }
+            // rows and chunks are multiples of 16 symbols: a 16-byte granule stays inside one row; an odd row reverses it
+            uint32_t rl, rn, od; row_of(v, a, rl, rn, od);
+            if (!od) { R[k] = *(const uint4*)(a.ystream + v); have |= 1u << k; }
+            else if (rn == a.il_w) {
+                const uint4 q = *(const uint4*)(a.ystream + (rl + (a.il_w - 16u - (v - rl))));
+                R[k] = make_uint4(__builtin_bswap32(q.w), __builtin_bswap32(q.z), __builtin_bswap32(q.y), __builtin_bswap32(q.x)); have |= 1u << k;
+            }                                                                        // else: the stream's last, shorter row -- placed byte by byte in commit()
+        }
+    };
+    if (regs && blockIdx.x < a.n_steps) fetch(blockIdx.x);
     for (uint32_t step = blockIdx.x; step < a.n_steps; step += gridDim.x) {
         const uint32_t U0 = step * a.span, U1 = (uint32_t)min((uint64_t)U0 + a.span, (uint64_t)a.n_sym);
-        // The de-interleave map is an involution inside every row segment (odd rows reversed, OLD:782-813): the step's pre-interleave
-        // symbols [U0, U1) are gathered straight from their mirrored places in the corrected stream, whatever the row width -- nothing
-        // but the step itself is read or staged.
         auto at = [&](uint32_t v) -> uint32_t { return a.sym_off + (v - U0); };     // LDS address of pre-interleave symbol v (U0: 16-byte aligned)
-        if (!a.il_on) {
-            for (uint32_t v = U0 + 16u * tid; v < U1; v += 16u * nthr) *(uint4*)(lds + at(v)) = *(const uint4*)(a.ystream + v);
-        } else if (a.il_fast) {
-            // rows and chunks are multiples of 16 symbols: a 16-byte granule stays inside one row; an odd row reverses it
-            for (uint32_t v = U0 + 16u * tid; v < U1; v += 16u * nthr) {
-                uint32_t rl, rn, od; row_of(v, a, rl, rn, od);
-                if (!od) *(uint4*)(lds + at(v)) = *(const uint4*)(a.ystream + v);
-                else if (rn == a.il_w) {
-                    const uint4 q = *(const uint4*)(a.ystream + (rl + (a.il_w - 16u - (v - rl))));
-                    *(uint4*)(lds + at(v)) = make_uint4(__builtin_bswap32(q.w), __builtin_bswap32(q.z), __builtin_bswap32(q.y), __builtin_bswap32(q.x));
-                } else {                                                        // the stream's last, shorter row
-                    for (uint32_t i = 0; i < 16u && v + i < rl + rn; ++i) lds[at(v + i)] = a.ystream[rl + (rn - 1u - (v + i - rl))];
-                }
+        if (regs) {
+#pragma unroll
+            for (uint32_t k = 0; k < G; ++k) {
+                const uint32_t v = U0 + 16u * (tid + k * nthr);
+                if (v >= U1) continue;
+                if (have >> k & 1u) *(uint4*)(lds + at(v)) = R[k];
+                else { uint32_t rl, rn, od; row_of(v, a, rl, rn, od); for (uint32_t i = 0; i < 16u && v + i < rl + rn; ++i) lds[at(v + i)] = a.ystream[rl + (rn - 1u - (v + i - rl))]; }
             }
+        } else if (!a.il_on) {
+            for (uint32_t v = U0 + 16u * tid; v < U1; v += 16u * nthr) *(uint4*)(lds + at(v)) = *(const uint4*)(a.ystream + v);
         } else {
             for (uint32_t v = U0 + tid; v < U1; v += nthr) {
                 uint32_t rl, rn, od; row_of(v, a, rl, rn, od);
@@ -151,6 +169,7 @@ __global__ __launch_bounds__(512, 2) void emit_stream_kernel(const EmitStArgs a)
             }
         }
         __syncthreads();
+        if (regs && step + gridDim.x < a.n_steps) fetch(step + gridDim.x);
         const uint64_t unit0 = (uint64_t)step * units_step;
         const uint32_t n_here = (uint32_t)min((uint64_t)units_step, a.n_units > unit0 ? a.n_units - unit0 : 0ull);
         const uint32_t y0 = at(U0);                                             // 16-byte aligned: span and lo16 are
