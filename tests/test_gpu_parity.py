@@ -182,6 +182,43 @@ def test_8k_frame_hash(gpu, orc, name):
     assert orc.crc32(enc) == ent["crc32"]
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("2-D rows of 7680 symbols (run flow)", dict(profile=4, uep=2, tile=(7680, 8))),
+    ("2-D rows of 1024 symbols + luma UEP (run flow, UEP kernel)", dict(profile=4, uep="luma", tile=(1024, 16))),
+    ("2-D 64x64, one k (pass flow)", dict(profile=4, uep=2, tile=(64, 64))),
+    ("four different k (two UEP launches by pairs of k)", dict(profile=1, uep=[0, 1, 2, 3, 0, 1, 2, 3, 0])),
+    ("three different k", dict(profile=1, uep=[0, 1, 1, 3, 0, 1, 3, 3, 0])),
+    ("luma UEP + beacon in the stores", dict(profile=1, uep="luma", beacon=(64, 4, 1))),
+    ("RS(26,20) + beacon every 2 words, slot 8", dict(profile=2, uep=2, beacon=(2, 8, 1))),
+])
+def test_4k_frame_round2_paths(gpu, orc, name, kw):
+    """The encode paths added in round 2, at a size that runs the persistent tile loop and its tickets for many rounds (3840 x 2160:
+    ~3,600 tiles on 768 workgroups): byte-exact against the oracle's CPU restatement in both modes, and the FIXED stream decodes back
+    to the pixels through the device entry points (fused decoder with the beacon stepped over, two-kernel decoder with the
+    destination-driven de-interleave)."""
+    import torch
+    NPX = 3840 * 2160
+    px = orc.lcg_pixels(NPX, 9001)
+    d_px = torch.from_numpy(px.view(np.uint8)).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    for mode in (0, 1):
+        cfg, ocfg = both(gpu, kw, mode)
+        cap = gpu.encoded_words(NPX // 2, cfg)
+        d_out = torch.zeros(cap * 9 + 64, dtype=torch.uint8, device="cuda")
+        n = gpu.encode_frame_dev(d_px.data_ptr(), NPX, cfg, d_out.data_ptr(), cap, s)
+        torch.cuda.synchronize()
+        rc, want = orc.encode_frame(px, ocfg, cap=NPX // 2 + NPX // 4)
+        assert rc == 0 and n == len(want), (name, mode, n, len(want))
+        got = d_out[: n * 9].cpu().numpy()
+        assert np.array_equal(got, np.asarray(want).reshape(-1)), (name, mode, np.flatnonzero(got != np.asarray(want).reshape(-1))[:8])
+        if mode == 1:
+            d_back = torch.zeros(NPX * 6 + 64, dtype=torch.uint8, device="cuda")
+            seen = gpu.default_cfg(); seen.mode = 1
+            rcd, nd = gpu.decode_profile_dev(d_out.data_ptr(), n, seen, d_back.data_ptr(), NPX, True, s)
+            torch.cuda.synchronize()
+            assert rcd == 0 and nd == NPX and torch.equal(d_back[: NPX * 6], d_px[: NPX * 6]), (name, rcd, nd)
+
+
 @pytest.mark.parametrize("name,kw,max_err", [
     ("C2 RS(26,20) 1-D (fused decoder)", dict(profile=2, uep=2), 3),                                # BASELINE configs[4]
     ("C2 clean", dict(profile=2, uep=2), 0),
