@@ -200,7 +200,9 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
                 waves = 8;
             }
             if (waves > (pass == 0 ? 8u : (uint32_t)kMaxWaves)) break;   // pass 0: 512-thread workgroups, three per CU
-            const uint32_t groups = (uint32_t)((9 * Lq + il_extra) / GS) + 8, stage = groups * GB + 1024 + 32 + il_stage;   // +1 KiB: LDS-DMA pieces are whole
+            const uint32_t groups = (uint32_t)((9 * Lq + il_extra) / GS) + 8;
+            uint32_t stage = groups * GB + 1024 + 32 + il_stage;                                              // +1 KiB: LDS-DMA pieces are whole
+            if (il_async == 1u) stage = std::max<uint32_t>(stage, (uint32_t)(9 * Lq) + 64u);                  // the permutation pass writes the tile's 9 Lq symbols into the consumed stage buffer (RGB input is smaller than that)
             const uint32_t total = hdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq) + il_extra) + kSymBack + ((il2d && !il_async) ? 1u : 2u) * round16(stage) + (fe == FE_RGB ? 256u : 0u);
             if (total > budget) break;
             // wave-instructions per stream symbol: phase 2 costs ~180 per wave, phase 1 (pixels) ~120 per wave-iteration
@@ -234,7 +236,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     }
     a.n_items = nw; a.n_tiles = n_tiles;
     { uint32_t acc = 0; for (int b = 0; b < 9; ++b) { a.band_first[b] = acc; acc += a.band_nb_tile[b]; } a.band_first[9] = acc; }
-    a.stage_stride = round16(a.stage_groups * GB + 1024 + 32 + il_stage);
+    a.stage_stride = round16(std::max<uint32_t>(a.stage_groups * GB + 1024 + 32 + il_stage, il_async == 1u ? 9u * Lq + 64u : 0u));
     a.lds_bytes = a.stage_off + ((il2d && !il_async) ? 1u : 2u) * a.stage_stride;   // pipelined flow: two stage buffers (the next tile streams in early)
     if (fe == FE_RGB) { a.qt_off = a.lds_bytes; a.lds_bytes += 256u; }                            // chroma quantiser table of the fused bridge
     a.il_async = il_async;

@@ -764,6 +764,30 @@ def test_rgb_fused_all_colours(t3, orc, gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(profile=4, uep=2, tile=(64, 64)), dict(profile=4, uep="luma", tile=(1024, 16)), dict(profile=4, uep=1, tile=(7, 5)),
+                                dict(profile=1, uep="luma"), dict(profile=2, uep=2, beacon=(64, 4, 1)), dict(profile=1, uep=[0, 1, 2, 3, 0, 1, 2, 3, 0])])
+def test_rgb_fused_other_flows(t3, orc, gpu, kw):
+    """The fused RGB front end through the other flows of the encode kernel (2-D with pass / run flow / odd geometry, UEP, beacon in the
+    stores, pair launches): 1.5 M random colours, odd pixel count, against the oracle's bridge + encoder; bridge parity unpinned."""
+    import torch
+    n = 1500001
+    rng = np.random.default_rng(11)
+    rgb = rng.integers(0, 256, 3 * n, dtype=np.uint8)
+    q = orc.rgb_to_quant(rgb)
+    s = torch.cuda.current_stream().cuda_stream
+    d_rgb = torch.from_numpy(rgb).cuda()
+    for mode in (0, 1):
+        cfg, ocfg = both(gpu, kw, mode)
+        rc, want = orc.encode_frame(q, ocfg, cap=n); assert rc == 0
+        n_cap = t3.encoded_words((n + 1) // 2, cfg)
+        d_out = torch.zeros(n_cap * 9 + 64, dtype=torch.uint8, device="cuda")
+        assert t3.encode_rgb_dev(d_rgb.data_ptr(), n, cfg, d_out.data_ptr(), n_cap, s) == len(want)
+        torch.cuda.synchronize()
+        got = d_out[: 9 * len(want)].cpu().numpy()
+        assert np.array_equal(got, np.asarray(want).reshape(-1)), (kw, mode, np.flatnonzero(got != np.asarray(want).reshape(-1))[:8])
+
+
+@pytest.mark.gpu
 def test_host_api_two_threads(gpu, orc):
     """The std::vector-shaped entry points share one stream and two scratch slots inside the library; two caller threads encoding
     and decoding DIFFERENT frames of different sizes at the same time must each get their own frame's bytes (the library holds
