@@ -788,6 +788,38 @@ def test_rgb_fused_other_flows(t3, orc, gpu, kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(profile=4, uep=2, tile=(64, 64)), dict(profile=4, uep="luma", tile=(1024, 16)), dict(profile=4, uep=1, tile=(7, 5)),
+                                dict(profile=1, uep="luma"), dict(profile=2, uep=2, beacon=(64, 4, 1)), dict(profile=1, uep=[0, 1, 2, 3, 0, 1, 2, 3, 0]),
+                                dict(profile=4, uep=[0, 1, 2, 3, 0, 1, 2, 3, 0], tile=(640, 3), beacon=(5, 0, 1))])
+def test_raw_word_input_other_flows(gpu, orc, kw):
+    """encode_profile_from_raw (26-trit words in, OLD:1043) through the flows of the encode kernel that the pixel tests above reach
+    with the packer fused: 700 k words (non-canonical trit 26 included), both modes, against the oracle; FIXED decodes back to the
+    words."""
+    import torch
+    n = 700001
+    rng = np.random.default_rng(12)
+    raw = rng.integers(0, 27, (n, 9), dtype=np.uint8)
+    d_raw = torch.from_numpy(raw).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    for mode in (0, 1):
+        cfg, ocfg = both(gpu, kw, mode)
+        rc, want = orc.encode_profile(raw, ocfg, cap=2 * n); assert rc == 0
+        n_cap = gpu.encoded_words(n, cfg)
+        d_out = torch.zeros(n_cap * 9 + 64, dtype=torch.uint8, device="cuda")
+        assert gpu.encode_profile_dev(d_raw.data_ptr(), n, cfg, d_out.data_ptr(), n_cap, s) == len(want)
+        torch.cuda.synchronize()
+        got = d_out[: 9 * len(want)].cpu().numpy()
+        assert np.array_equal(got, np.asarray(want).reshape(-1)), (kw, mode, np.flatnonzero(got != np.asarray(want).reshape(-1))[:8])
+        if mode == 1:
+            d_back = torch.zeros(n * 9 + 64, dtype=torch.uint8, device="cuda")
+            seen = gpu.default_cfg(); seen.mode = 1
+            rcd, nd = gpu.decode_profile_dev(d_out.data_ptr(), len(want), seen, d_back.data_ptr(), n, False, s)
+            torch.cuda.synchronize()
+            canon = raw.copy(); canon[:, 8] = raw[:, 8] % 9                         # trit 26 of a word is not carried (OLD:1068-1076)
+            assert rcd == 0 and nd == n and np.array_equal(d_back[: n * 9].cpu().numpy().reshape(-1, 9), canon), (kw, rcd, nd)
+
+
+@pytest.mark.gpu
 def test_host_api_two_threads(gpu, orc):
     """The std::vector-shaped entry points share one stream and two scratch slots inside the library; two caller threads encoding
     and decoding DIFFERENT frames of different sizes at the same time must each get their own frame's bytes (the library holds
