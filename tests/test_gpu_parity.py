@@ -820,6 +820,33 @@ def test_raw_word_input_other_flows(gpu, orc, kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("uep", [0, 1, 2, 3])
+@pytest.mark.parametrize("beacon", [(0, 0, 0), (7, 3, 1)])
+def test_rgb_out_every_code(t3, orc, gpu, uep, beacon):
+    """RGB out of the fused decoder for each of the four codes, with and without a beacon stepped over in its loads, 0..t errors in
+    every block (no beacon) / a clean stream (beacon): equals the oracle's dequantisation of the pixels; odd pixel count."""
+    import torch
+    n = 400001
+    rng = np.random.default_rng(20 + uep)
+    px = rand_pixels(rng, n)
+    cfg = gpu.make_cfg(profile=uep, uep=uep, beacon=beacon, mode=1)
+    s = torch.cuda.current_stream().cuda_stream
+    d_px = torch.from_numpy(px.view(np.uint8).copy()).cuda()
+    n_cap = t3.encoded_words((n + 1) // 2, cfg)
+    d_out = torch.zeros(n_cap * 9 + 64, dtype=torch.uint8, device="cuda")
+    nw = gpu.encode_frame_dev(d_px.data_ptr(), n, cfg, d_out.data_ptr(), n_cap, s)
+    L = gpu.plan((n + 1) // 2, cfg)
+    if not beacon[2]:
+        gpu.inject_errors_dev(d_out.data_ptr(), L.header_syms, L.body_syms // 26, 31 + uep, (26 - max(L.band_k)) // 2, s)
+    d_rgb = torch.full((3 * n + 64,), 0, dtype=torch.uint8, device="cuda"); ver = torch.full((2,), 9, dtype=torch.int32, device="cuda")
+    t3.decode_rgb_async(d_out.data_ptr(), nw, cfg, n, d_rgb.data_ptr(), ver.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert ver.cpu().numpy().tolist() == [0, 0]
+    assert np.array_equal(d_rgb[: 3 * n].cpu().numpy(), np.asarray(orc.quant_to_rgb(px)).reshape(-1)), (uep, beacon)
+    assert int(d_rgb[3 * n:].sum().item()) == 0
+
+
+@pytest.mark.gpu
 def test_host_api_two_threads(gpu, orc):
     """The std::vector-shaped entry points share one stream and two scratch slots inside the library; two caller threads encoding
     and decoding DIFFERENT frames of different sizes at the same time must each get their own frame's bytes (the library holds
