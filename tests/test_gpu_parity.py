@@ -876,6 +876,48 @@ def test_host_api_two_threads(gpu, orc):
 
 
 @pytest.mark.gpu
+def test_device_entry_points_two_streams(t3, orc, gpu):
+    """The *_dev entry points of ONE context on two HIP streams from two threads at the same time (and on hipStreamPerThread, one
+    handle value that is a different stream per thread): per-stream intermediates and tile-ticket counters, so the frames cannot
+    take each other's tiles or scratch.  Large frames (2K x 2K, beacon and two-kernel decode paths included) so that the kernels
+    really overlap; every result against the oracle / the round trip."""
+    import threading
+    import torch
+    HIP_STREAM_PER_THREAD = 2
+    res = {}
+    def work(tag, seed, kw, use_spt):
+        try:
+            n = 2048 * 2048 + 2 * seed
+            st = None if use_spt else torch.cuda.Stream()
+            sh = HIP_STREAM_PER_THREAD if use_spt else st.cuda_stream
+            cfg, ocfg = both(gpu, kw, mode=1)
+            px = orc.lcg_pixels(n, seed)
+            rc, want = orc.encode_frame(px, ocfg, cap=n); assert rc == 0
+            d_px = torch.from_numpy(px.view(np.uint8).copy()).cuda()
+            cap = gpu.encoded_words(n // 2, cfg)
+            d_out = torch.zeros(cap * 9 + 64, dtype=torch.uint8, device="cuda"); d_back = torch.zeros(n * 6 + 64, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            for rep in range(12):
+                d_out.zero_(); d_back.zero_(); torch.cuda.synchronize()
+                nw = gpu.encode_frame_dev(d_px.data_ptr(), n, cfg, d_out.data_ptr(), cap, sh)
+                seen = gpu.default_cfg(); seen.mode = 1
+                rcd, nd = gpu.decode_profile_dev(d_out.data_ptr(), nw, seen, d_back.data_ptr(), n, True, sh)     # synchronises `sh`
+                assert nw == len(want) and rcd == 0 and nd == n, (tag, rep, nw, rcd, nd)
+                assert np.array_equal(d_out[: 9 * nw].cpu().numpy(), np.asarray(want).reshape(-1)), (tag, rep, "encode")
+                assert torch.equal(d_back[: 6 * n], d_px[: 6 * n]), (tag, rep, "decode")
+            res[tag] = "ok"
+        except Exception as e:   # noqa: BLE001
+            res[tag] = repr(e)
+    for use_spt in (False, True):
+        res.clear()
+        th = [threading.Thread(target=work, args=("a", 5, dict(profile=2, uep=2, beacon=(64, 4, 1)), use_spt)),
+              threading.Thread(target=work, args=("b", 9, dict(profile=4, uep="luma", tile=(64, 64)), use_spt))]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert res == {"a": "ok", "b": "ok"}, (use_spt, res)
+
+
+@pytest.mark.gpu
 def test_two_contexts_two_threads(t3, orc, gpu):
     """One handle per GPU (t3hip_create / t3hip_use): two contexts (both on device 0 here: the box has one card) driven by two
     threads at the same time, each encoding and decoding its own frames on its own stream, tables and scratch; the default
