@@ -234,7 +234,20 @@ def main():
     t3 = ge.load_package()
     sf = __import__("ternary_image_codec_amd.superframe", fromlist=["x"])
     t3.init(local)
-    comm = sf.make_comm() if (multi and not rehearse) else None        # the library's own RCCL communicator (t3hip_comm_create)
+    comm, exchange_via = None, None
+    if multi and not rehearse:                                         # the library's own RCCL communicator (t3hip_comm_create)
+        # all ranks must take the same path: a rank that cannot create the communicator tells the others (gloo), and everybody then uses
+        # torch.distributed's all-gather (RCCL as well) so that the scaling run still completes -- reported in config.exchange
+        try:
+            comm = sf.make_comm(); ok_local = 1
+        except Exception as e:   # noqa: BLE001
+            print("bench.py: rank %d: t3hip communicator failed (%r)" % (rank, e), file=sys.stderr); ok_local = 0
+        flag = torch.tensor([ok_local]); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            comm = None
+        exchange_via = "t3hip_index_allgather (RCCL, library entry)" if comm is not None else "torch.distributed.all_gather_into_tensor (RCCL; the library communicator could not be created)"
+    elif rehearse:
+        exchange_via = "gloo on CPU copies (one-card rehearsal)"
     orc = ol.oracle()
     cur = torch.cuda.current_stream()
     stream = cur.cuda_stream
@@ -301,6 +314,8 @@ def main():
         """The one exchange step: the batch's index records, all-gathered (RCCL; gloo on CPU copies in the one-card rehearsal)."""
         if rehearse:
             return sf.gather_records_torch(d_recs.cpu())
+        if comm is None:
+            return sf.gather_records_torch(d_recs)
         return sf.gather_records(comm, d_recs)
 
     # clock settling, untimed and in addition to the W warm-up steps: the card needs tens of milliseconds of continuous work to
@@ -391,7 +406,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "one 7680x4320 frame per rank per step (BASELINE configs[1]; %d distinct frames resident per rank, global frame f = rank + N j, LCG seed 12345 + f: configs[3]): fused encode COMPAT P3 RS(26,20) 1-D, then FIXED-mode decode of the same frame with 0..3 injected symbol errors per block (" % FPR + ("synchronous entry, header parsed on the host per frame" if args.sync_decode else "streaming entry: configuration from the stream's first frame, header symbols checked on the device") + "), then index record" + (" [encode only]" if args.encode_only else ""),
                    "frame_px": NPX, "coded_words": n_enc, "frames_per_rank": FPR, "settle_ms": args.settle_ms, "settle_steps": settle_steps,
-                   "sharding": "frames per rank, no data-path collective; one RCCL all-gather (t3hip_index_allgather) of index records per batch" + (" [one-card rehearsal: gloo]" if rehearse else "")},
+                   "sharding": "frames per rank, no data-path collective; one all-gather of index records per batch", "exchange": exchange_via},
         "encode_ms": round(enc_avg, 4), "decode_ms": round(dec_avg, 4),
         "encode_mpix_s": round(NPX / enc_avg / 1e3, 1), "decode_mpix_s": round(NPX / dec_avg / 1e3, 1),
         "roofline": {"kernel": "encode_kernel_k<FE_PIXELS, 1-D, r=6>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
