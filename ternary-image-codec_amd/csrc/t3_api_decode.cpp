@@ -43,6 +43,7 @@ namespace {
 #define d_flag_map    T3_SLOT(uint32_t*, 11)
 #define d_synd_lut    (&T3_SLOT(uint32_t*, 12)) // [4] per k index: syndrome LUT of the two-kernel decoder
 #define d_roots       (&T3_SLOT(uint32_t*, 16)) // [4] per k index: the Chien search (OLD:611-623) of every locator, tabulated
+#define d_crc_afrag4  T3_SLOT(uint32_t*, 24)    // ... of its FP4 form (t3_crc_fp4.hip)
 #define d_synd_afrag  (&T3_SLOT(uint32_t*, 20)) // [4] per k index: A operand of the syndrome MFMA (t3_host.hpp build_mfma_syndrome)
 uint32_t synd_lut_bytes[4] = {0, 0, 0, 0};      // (a size, the same for every context)
 
@@ -381,7 +382,7 @@ void rgb_shutdown();
 void decode_shutdown() {
     std::lock_guard<std::mutex> lk(g_tab_mu);
     auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
-    fr(d_zpow); fr(d_crc_acc); fr(d_crc_afrag); fr(d_fxtab); fr(d_fma); fr(d_rgb_dq);
+    fr(d_zpow); fr(d_crc_acc); fr(d_crc_afrag); fr(d_crc_afrag4); fr(d_fxtab); fr(d_fma); fr(d_rgb_dq);
     if (h_mail) { (void)hipHostFree(h_mail); h_mail = nullptr; }
     if (h_flag) { (void)hipHostFree(h_flag); h_flag = nullptr; d_flag_map = nullptr; }
     rgb_shutdown();
@@ -411,6 +412,19 @@ int decode_init(const RsTables*) {
         }
         HIPCHK(hipMalloc((void**)&d_crc_afrag, af.size() * 4));
         HIPCHK(hipMemcpy(d_crc_afrag, af.data(), af.size() * 4, hipMemcpyHostToDevice));
+        // FP4 form (t3_crc_fp4.hip): 8 data slices (K slot p = 8 d + i of lane half kh in step s carries bit i of byte 32 kh + 4 s + d of the
+        // chunk), the feedback slice and five "append 64 * 2^b bytes" slices (K slot j < 16 of half kh carries the remainder bit in
+        // accumulator row (j & 3) + 8 (j >> 2) + 4 kh; slots 16..31 unused).  A set bit is FP4 1.0 = 0b0010 in nibble p of the lane's 16 bytes.
+        std::vector<uint32_t> a4((size_t)14 * 64 * 4, 0u);
+        for (int st = 0; st < 14; ++st) for (int kh = 0; kh < 2; ++kh) for (int pos = 0; pos < 32; ++pos) {
+            uint32_t vec;
+            if (st < 8) { const int d = pos >> 3, i = pos & 7, o = 32 * kh + 4 * st + d; vec = adv(tbl[1u << i], 63u - (uint32_t)o); }
+            else if (pos < 16) vec = adv(1u << ((pos & 3) + 8 * (pos >> 2) + 4 * kh), st == 8 ? 2048u : 64u << (st - 9));
+            else continue;
+            for (int m = 0; m < 32; ++m) if (vec >> m & 1u) a4[((size_t)st * 64 + m + 32 * kh) * 4 + (pos >> 3)] |= 2u << (4 * (pos & 7));
+        }
+        HIPCHK(hipMalloc((void**)&d_crc_afrag4, a4.size() * 4));
+        HIPCHK(hipMemcpy(d_crc_afrag4, a4.data(), a4.size() * 4, hipMemcpyHostToDevice));
     }
     {   // field tables of the fused decoder
         const Field& F = field();
@@ -562,7 +576,10 @@ static int launch_crc(const uint8_t* d_data, uint64_t n_bytes, uint32_t* acc, hi
         m.rounds_per_wave = rpw_env > 0 ? (uint32_t)rpw_env : (uint32_t)std::max<uint64_t>(8, (m.n_rounds + slots - 1) / slots);
         m.afrag = d_crc_afrag; m.zpow = d_zpow; m.chunk_crc = acc; m.sym_sum = acc + 1;
         const uint64_t waves = ((uint64_t)m.n_rounds + m.rounds_per_wave - 1) / m.rounds_per_wave;
-        hipLaunchKernelGGL(crc_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, m); HIPCHK(hipGetLastError());
+        static const bool use_i8 = getenv("T3HIP_CRC_I8") != nullptr;            // measurement knob: the i8 form (t3_crc_mfma.hip)
+        if (use_i8) hipLaunchKernelGGL(crc_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, m);
+        else { m.afrag = d_crc_afrag4; hipLaunchKernelGGL(crc_fp4_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, m); }
+        HIPCHK(hipGetLastError());
         done = (uint64_t)m.n_rounds << 11;
     }
     if (tail_off) { *tail_off = n_bytes; if (done && n_bytes - done < 2048) { *tail_off = done; return T3_OK; } }

@@ -149,6 +149,7 @@ __global__ void inject_errors_kernel(uint8_t* syms, uint64_t n_blocks, uint32_t 
 __global__ void hdr_compare_kernel(const uint8_t* in, HdrExpect expect, uint32_t n, uint32_t* mismatch);
 __global__ void crc_chunks_kernel(const CrcArgs a);
 __global__ void crc_mfma_kernel(const CrcMArgs a);
+__global__ void crc_fp4_kernel(const CrcMArgs a);          // the same on the FP4 matrix instruction (t3_crc_fp4.hip); afrag = [14][64][4] FP4 slices
 __global__ void frame_record_kernel(const uint32_t* acc, uint32_t lead, const uint8_t* tail, uint32_t tail_len, const uint32_t* zpow,
                                     const uint8_t* words, uint64_t n_words, uint64_t frame_idx, uint32_t profile, uint32_t mode, void* rec);
 #endif
