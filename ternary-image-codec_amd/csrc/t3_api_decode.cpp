@@ -576,7 +576,7 @@ static int launch_crc(const uint8_t* d_data, uint64_t n_bytes, uint32_t* acc, hi
         m.rounds_per_wave = rpw_env > 0 ? (uint32_t)rpw_env : (uint32_t)std::max<uint64_t>(8, (m.n_rounds + slots - 1) / slots);
         m.afrag = d_crc_afrag; m.zpow = d_zpow; m.chunk_crc = acc; m.sym_sum = acc + 1;
         const uint64_t waves = ((uint64_t)m.n_rounds + m.rounds_per_wave - 1) / m.rounds_per_wave;
-        static const bool use_i8 = getenv("T3HIP_CRC_I8") != nullptr;            // measurement knob: the i8 form (t3_crc_mfma.hip)
+        const bool use_i8 = getenv("T3HIP_CRC_I8") != nullptr;                   // measurement / test knob: the i8 form (t3_crc_mfma.hip)
         if (use_i8) hipLaunchKernelGGL(crc_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, m);
         else { m.afrag = d_crc_afrag4; hipLaunchKernelGGL(crc_fp4_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, m); }
         HIPCHK(hipGetLastError());

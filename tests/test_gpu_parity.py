@@ -373,8 +373,11 @@ def test_error_injector_matches_host(gpu, orc):
     assert np.array_equal(d.cpu().numpy(), orc.inject_errors(w, 52, 390, 99, 3))
 
 
-def test_frame_record(gpu, orc):
+@pytest.mark.parametrize("crc_kernel", ["fp4", "i8"])
+def test_frame_record(gpu, orc, crc_kernel, monkeypatch):
     import torch
+    if crc_kernel == "i8":
+        monkeypatch.setenv("T3HIP_CRC_I8", "1")          # the i8 form of the matrix-core CRC (the FP4 form is the default)
     rng = np.random.default_rng(4)
     # the last sizes go through the matrix-core rounds; their rests (9 n mod 2048 = 4 .. 2047) are taken by the record kernel itself
     for n in (0, 1, 6, 255, 256, 257, 100000) + tuple(range(14564, 14564 + 228, 19)) + (14564 + 227, 16384, 20766726 // 64):
