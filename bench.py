@@ -210,7 +210,7 @@ def main():
     if os.environ.get("T3_BENCH_RANK_PROBE") == "1":       # CPU test of the self-launch: rendezvous over gloo, report, leave (no GPU call)
         dist.init_process_group("gloo")
         t = torch.tensor([rank + 1]); dist.all_reduce(t)
-        print("probe rank %d of %d sum %d" % (rank, world, int(t.item())), flush=True)
+        os.write(1, ("probe rank %d of %d sum %d\n" % (rank, world, int(t.item()))).encode())     # one write: two ranks share the pipe
         dist.destroy_process_group()
         return
     # T3_BENCH_REHEARSE_ONE_GPU=1: dry run of the N>1 control flow on a single card (every rank on cuda:0, the exchange over
@@ -236,16 +236,10 @@ def main():
     t3.init(local)
     comm, exchange_via = None, None
     if multi and not rehearse:                                         # the library's own RCCL communicator (t3hip_comm_create)
-        # all ranks must take the same path: a rank that cannot create the communicator tells the others (gloo), and everybody then uses
-        # torch.distributed's all-gather (RCCL as well) so that the scaling run still completes -- reported in config.exchange
-        try:
-            comm = sf.make_comm(); ok_local = 1
-        except Exception as e:   # noqa: BLE001
-            print("bench.py: rank %d: t3hip communicator failed (%r)" % (rank, e), file=sys.stderr); ok_local = 0
-        flag = torch.tensor([ok_local]); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            comm = None
-        exchange_via = "t3hip_index_allgather (RCCL, library entry)" if comm is not None else "torch.distributed.all_gather_into_tensor (RCCL; the library communicator could not be created)"
+        # make_comm returns a communicator on every rank or None on every rank (probe, agree, then rendezvous: superframe.py); without
+        # one everybody uses torch.distributed's all-gather (RCCL as well), so the scaling run still completes -- reported in config.exchange
+        comm = sf.make_comm()
+        exchange_via = "t3hip_index_allgather (RCCL, library entry)" if comm is not None else "torch.distributed.all_gather_into_tensor (RCCL; the library communicator could not be created on every rank)"
     elif rehearse:
         exchange_via = "gloo on CPU copies (one-card rehearsal)"
     orc = ol.oracle()
@@ -345,15 +339,16 @@ def main():
         step(i, events[i])
     if s2 is not None:
         cur.wait_stream(s2)
+    ex_ev = (t3.Event(), t3.Event())
     if multi and not args.encode_only:
+        ex_ev[0].record(stream); t_ex = time.perf_counter()
         gathered = exchange()
+        ex_ev[1].record(stream); exchange_host_ms = (time.perf_counter() - t_ex) * 1e3
     torch.cuda.synchronize()
     if not args.encode_only and not args.sync_decode:      # the streaming entry's verdicts: header as expected, no uncorrectable block
         verdicts = d_verdict[: args.steps].cpu().numpy()
         assert args.no_verify or not verdicts.any(), verdicts
-    if multi:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0                          # (no barrier here: the MAX over ranks below is the job's time)
     if multi:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -407,10 +402,14 @@ def main():
         "config": {"workload": "one 7680x4320 frame per rank per step (BASELINE configs[1]; %d distinct frames resident per rank, global frame f = rank + N j, LCG seed 12345 + f: configs[3]): fused encode COMPAT P3 RS(26,20) 1-D, then FIXED-mode decode of the same frame with 0..3 injected symbol errors per block (" % FPR + ("synchronous entry, header parsed on the host per frame" if args.sync_decode else "streaming entry: configuration from the stream's first frame, header symbols checked on the device") + "), then index record" + (" [encode only]" if args.encode_only else ""),
                    "frame_px": NPX, "coded_words": n_enc, "frames_per_rank": FPR, "settle_ms": args.settle_ms, "settle_steps": settle_steps,
                    "sharding": "frames per rank, no data-path collective; one all-gather of index records per batch", "exchange": exchange_via},
+        "exchange_ms": (round(ex_ev[0].elapsed_ms(ex_ev[1]), 4) if (multi and not args.encode_only) else None),
+        "exchange_host_ms": (round(exchange_host_ms, 4) if (multi and not args.encode_only) else None),
         "encode_ms": round(enc_avg, 4), "decode_ms": round(dec_avg, 4),
         "encode_mpix_s": round(NPX / enc_avg / 1e3, 1), "decode_mpix_s": round(NPX / dec_avg / 1e3, 1),
         "roofline": {"kernel": "encode_kernel_k<FE_PIXELS, 1-D, r=6>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc("pmc_encode_latest.json"), "algorithmic_bytes_per_launch": alg_bytes,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc("pmc_encode_latest.json"),
+                     "traffic_source": "profiles/pmc_encode_latest.json: rocprofv3 --pmc passes of this command in their own runs (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024, gfx950 correction), not measured in this run",
+                     "algorithmic_bytes_per_launch": alg_bytes,
                      "launch_ms": round(enc_avg, 4),
                      "note": "north-star kernel (SURVEY 8d); launch_ms = HIP events around the launch inside the timed loop"},
     }
@@ -418,7 +417,7 @@ def main():
         dec_bytes = 9 * n_fenc + 6 * NPX
         out["roofline_decode"] = {"kernel": "decode_fixed_px_kernel<r=6, pixels>" + (" (+ header read-back and failure-flag sync of the synchronous entry point)" if args.sync_decode else " (+ header check kernel)"),
                                   "bound": "hbm", "achieved": round(dec_bytes / (dec_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(dec_bytes / (dec_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc("pmc_decode_latest.json"),
+                                  "frac": round(dec_bytes / (dec_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc("pmc_decode_latest.json"), "traffic_source": "profiles/pmc_decode_latest.json (separate rocprofv3 --pmc runs of this command)",
                                   "algorithmic_bytes_per_launch": dec_bytes, "launch_ms": round(dec_avg, 4)}
     if world == 1 and not args.no_verify:                  # reported beside the line, on rank 0 at N=1 only
         if not args.encode_only and not args.no_rgb:

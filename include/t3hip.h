@@ -219,6 +219,11 @@ int t3hip_rs_decode_blocks_dev(int k, int mode, uint8_t* d_code26, uint64_t n_bl
  * download.  data_k of a block whose decode fails is returned as it came in (the reference leaves out_k untouched). */
 int t3hip_rs_encode_blocks(int k, int mode, const uint8_t* data_k, uint64_t n_blocks, uint8_t* code26);
 int t3hip_rs_decode_blocks(int k, int mode, uint8_t* code26_inout, uint64_t n_blocks, uint8_t* data_k, uint8_t* ok);
+/* ONE block, on the host (no device, no launch): what RSCodec::encode_block / decode_block bind when a caller walks blocks one at a
+ * time (the reference's self-test OLD:1172-1207, its header RS OLD:1142-1158).  26 bytes are control data, like the header codec;
+ * same parity matrix / decoder as the kernels.  decode returns 1 (decode_block true), 0 (false; out_k untouched) or T3_E_ARG. */
+int t3hip_rs_encode_block_host(int k, int mode, const uint8_t* data_k, uint8_t* code26);
+int t3hip_rs_decode_block_host(int k, int mode, uint8_t* code26_inout, uint8_t* data_k);
 
 /* ---- the reference's symbol-level public helpers --------------------------------------------------------
  * Single symbols and the header are control data: host arithmetic on the tables the kernels are built from.
@@ -265,6 +270,10 @@ int t3hip_index_assemble(t3_frame_record* recs, uint64_t n_recs, uint64_t first_
  * RCCL is bound at run time (dlopen librccl.so.1); without it these return T3_E_COMM. */
 #define T3_COMM_ID_BYTES 128
 typedef struct t3_comm t3_comm;
+/* T3_OK when RCCL can be bound in this process, T3_E_COMM otherwise; no collective, no device call.  A multi-rank host probes this on
+ * EVERY rank and agrees on the result (its own control channel) before anyone draws an id or calls t3hip_comm_create: a rank that
+ * cannot bind must not leave the others waiting inside ncclCommInitRank. */
+int t3hip_comm_available(void);
 int t3hip_comm_unique_id(uint8_t id[T3_COMM_ID_BYTES]);
 int t3hip_comm_create(const uint8_t id[T3_COMM_ID_BYTES], int world, int rank, t3_comm** out);
 int t3hip_comm_destroy(t3_comm* c);

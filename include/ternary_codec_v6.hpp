@@ -97,11 +97,7 @@ struct DecoderConfigSeen {
     CosetID coset = CosetID::C0;
     uint8_t mode = T3_MODE_COMPAT;
 };
-// The reference's contexts own GF tables and five RSCodec objects; here those constants live in the library
-// (device-resident, built once in t3hip_init), so a context is just its configuration — and, unlike the
-// reference's (raw pointer into itself, OLD:492), safely copyable.
-struct EncoderContext { EncoderConfig cfg; EncoderContext() { uep_uniform(cfg.uep, 1); } };
-struct DecoderContext { DecoderConfigSeen cfg_last_seen; DecoderContext() { uep_uniform(cfg_last_seen.uep, 1); } };
+// (EncoderContext / DecoderContext: below, after GF27Context and RSCodec, which they own as in OLD:885-916)
 
 // ---- header (OLD:155-380) ----------------------------------------------------------------------------------------
 struct SuperframeHeader {
@@ -162,24 +158,54 @@ struct GF27Context {
     GF27 pow_alpha(int e) const { return tab.exp[(e % 26 + 26) % 26]; }
     int log(GF27 a) const { return tab.log[a]; }
 };
-// One block per call through the block-level kernels (t3hip_rs_encode_blocks / t3hip_rs_decode_blocks): the reference's shape, fine
-// for its self-test and for header-sized work; whole frames go through encode_profile_from_raw / decode_profile_to_raw.
-// `mode` is build-side: T3_MODE_COMPAT = the reference's arithmetic (its parity map, Forney with add), T3_MODE_FIXED = v6c.
+// One block per call, as in the reference: 26 symbols are control data and are coded on the host (t3hip_rs_encode_block_host /
+// t3hip_rs_decode_block_host: the parity matrix and decoder the kernels are built from, no launch) -- a caller that walks blocks
+// one at a time, like the reference's self-test OLD:1172-1207, pays integer arithmetic, not 10 us per block.  Bulk work goes
+// through t3hip_rs_encode_blocks / t3hip_rs_decode_blocks (device) or, for whole frames, encode_profile_from_raw / decode_profile_to_raw.
+// `mode` is build-side: T3_MODE_COMPAT = the reference's arithmetic (its parity map, Forney with add), T3_MODE_FIXED = v6c; a codec
+// owned by a context follows that context's cfg.mode (mode_ref).
 struct RSCodec {
-    GF27Context* gf = nullptr; RSParams params{}; std::vector<GF27> g; uint8_t mode = T3_MODE_COMPAT;
+    GF27Context* gf = nullptr; RSParams params{}; std::vector<GF27> g; uint8_t mode = T3_MODE_COMPAT; const uint8_t* mode_ref = nullptr;
+    int arithmetic() const { return mode_ref ? *mode_ref : mode; }
     void init(GF27Context* c, RSParams p) { gf = c; params = p; build_gen(); }
     void build_gen() { g.assign((size_t)(params.n - params.k + 1), 0); if (t3hip_rs_generator(params.k, g.data()) != T3_OK) g.assign(1, 1); }   // OLD:501-516
-    bool encode_block(const GF27* data_k, GF27* out_n) const { return t3hip_rs_encode_blocks(params.k, mode, data_k, 1, out_n) == T3_OK; }   // OLD:517-535
+    bool encode_block(const GF27* data_k, GF27* out_n) const { return t3hip_rs_encode_block_host(params.k, arithmetic(), data_k, out_n) == T3_OK; }   // OLD:517-535
     GF27 poly_eval(const std::vector<GF27>& p, GF27 x) const {   // OLD:536-545 (Horner)
         GF27 acc = 0;
         for (int i = (int)p.size() - 1; i >= 0; --i) acc = gf27_add(gf27_mul_poly(acc, x), p[(size_t)i]);
         return acc;
     }
-    bool decode_block(GF27* inout_n, GF27* out_k) const {        // OLD:546-662: inout_n corrected in place, out_k only on success
-        uint8_t good = 0;
-        std::vector<GF27> keep(out_k, out_k + params.k);
-        if (t3hip_rs_decode_blocks(params.k, mode, inout_n, 1, out_k, &good) != T3_OK) { std::copy(keep.begin(), keep.end(), out_k); return false; }
-        return good != 0;
+    // OLD:546-662: inout_n corrected in place, out_k only on success
+    bool decode_block(GF27* inout_n, GF27* out_k) const { return t3hip_rs_decode_block_host(params.k, arithmetic(), inout_n, out_k) == 1; }
+};
+
+// ---- contexts (OLD:885-916): the field tables and the five codecs as members, so reference code that reaches into them
+// (ectx.rs_p3.encode_block(...), dctx.gf.mul(...)) compiles unchanged.  The codecs follow cfg.mode / cfg_last_seen.mode.  Unlike the
+// reference's (RSCodec::gf is a raw pointer into the owning context, OLD:492) these can be copied: a copy re-binds its own members.
+struct EncoderContext {
+    GF27Context gf; RSCodec rs_p1, rs_p2, rs_p3, rs_p4, rs_hdr; EncoderConfig cfg;
+    EncoderContext() { bind(); uep_uniform(cfg.uep, 1); }
+    EncoderContext(const EncoderContext& o) : cfg(o.cfg) { bind(); }
+    EncoderContext& operator=(const EncoderContext& o) { cfg = o.cfg; return *this; }
+private:
+    void bind() {
+        gf.init();
+        RSCodec* cs[5] = {&rs_p1, &rs_p2, &rs_p3, &rs_p4, &rs_hdr};
+        const RSParams ps[5] = {rs_params_for(ProfileID::P1_RS26_24), rs_params_for(ProfileID::P2_RS26_22), rs_params_for(ProfileID::P3_RS26_20), rs_params_for(ProfileID::P4_RS26_18), RSParams{26, 18}};
+        for (int i = 0; i < 5; ++i) { cs[i]->init(&gf, ps[i]); cs[i]->mode_ref = &cfg.mode; }
+    }
+};
+struct DecoderContext {
+    GF27Context gf; RSCodec rs_p1, rs_p2, rs_p3, rs_p4, rs_hdr; DecoderConfigSeen cfg_last_seen;
+    DecoderContext() { bind(); uep_uniform(cfg_last_seen.uep, 1); }
+    DecoderContext(const DecoderContext& o) : cfg_last_seen(o.cfg_last_seen) { bind(); }
+    DecoderContext& operator=(const DecoderContext& o) { cfg_last_seen = o.cfg_last_seen; return *this; }
+private:
+    void bind() {
+        gf.init();
+        RSCodec* cs[5] = {&rs_p1, &rs_p2, &rs_p3, &rs_p4, &rs_hdr};
+        const RSParams ps[5] = {rs_params_for(ProfileID::P1_RS26_24), rs_params_for(ProfileID::P2_RS26_22), rs_params_for(ProfileID::P3_RS26_20), rs_params_for(ProfileID::P4_RS26_18), RSParams{26, 18}};
+        for (int i = 0; i < 5; ++i) { cs[i]->init(&gf, ps[i]); cs[i]->mode_ref = &cfg_last_seen.mode; }
     }
 };
 
@@ -206,15 +232,24 @@ struct HeaderCodec {
 // ---- RAW packer primitives (OLD:675-722) ---------------------------------------------------------------------------------
 inline void i2tr(uint32_t v, int w, std::array<UTrit, 27>& d, int s) { for (int i = 0; i < w; ++i) { d[(size_t)(s + i)] = (UTrit)(v % 3); v /= 3; } }
 inline uint32_t tr2i(const std::array<UTrit, 27>& d, int w, int s) { uint32_t val = 0, p = 1; for (int i = 0; i < w; ++i) { val += p * d[(size_t)(s + i)]; p *= 3; } return val; }
-inline void pack_two_pixels(const PixelYCbCrQuant& a, const PixelYCbCrQuant& b, Word27& w) {          // OLD:693-705, one word through K1
-    const PixelYCbCrQuant two[2] = {a, b};
-    if (!t3hip_is_ready()) t3hip_init(0);
-    t3hip_pack_pixels(two, 2, &w);
+// One word = 26 trits = one integer below 3^26 < 2^42: the components are digit runs of it (Y: 5 trits, Cb + 40 and Cr + 40: 4 each,
+// pixel b 13 trits further up, trit 26 = 0), the nine symbols are its base-27 digits.  Host integer arithmetic, no device: a
+// caller that loops these as OLD:728-733 does pays nanoseconds per word.  No clamping, as in the reference: a component enters
+// as (uint32 cast) mod 3^width (OLD:675-682, 697-702).
+inline void pack_two_pixels(const PixelYCbCrQuant& a, const PixelYCbCrQuant& b, Word27& w) {          // OLD:693-705
+    auto px13 = [](const PixelYCbCrQuant& p) -> uint64_t {
+        return (uint64_t)((uint32_t)p.Yq % 243u) + 243ull * ((uint32_t)((int)p.Cbq + 40) % 81u) + 19683ull * ((uint32_t)((int)p.Crq + 40) % 81u);
+    };
+    uint64_t v = px13(a) + 1594323ull * px13(b);                      // 3^13
+    for (int s = 0; s < SYM_PER_WORD; ++s) { w.sym[(size_t)s] = (GF27)(v % 27u); v /= 27u; }
 }
-inline void unpack_two_pixels(const Word27& w, PixelYCbCrQuant& a, PixelYCbCrQuant& b) {            // OLD:706-722, one word through K5
-    PixelYCbCrQuant two[2];
-    if (!t3hip_is_ready()) t3hip_init(0);
-    if (t3hip_unpack_words(&w, 1, two) == T3_OK) { a = two[0]; b = two[1]; }
+inline void unpack_two_pixels(const Word27& w, PixelYCbCrQuant& a, PixelYCbCrQuant& b) {            // OLD:706-722 (unpack3 reduces every digit; trit 26 ignored)
+    uint64_t v = 0;
+    for (int s = SYM_PER_WORD - 1; s >= 0; --s) v = 27u * v + w.sym[(size_t)s] % 27u;
+    auto px13 = [](uint64_t u, PixelYCbCrQuant& p) {
+        p.Yq = (uint16_t)(u % 243u); p.Cbq = (int16_t)((int)(u / 243u % 81u) - 40); p.Crq = (int16_t)((int)(u / 19683u % 81u) - 40);
+    };
+    px13(v % 1594323ull, a); px13(v / 1594323ull % 1594323ull, b);
 }
 // ---- 2-D boustrophedon on a symbol vector (OLD:750-813) --------------------------------------------------------------------
 inline void interleave2D_boustrophedon(std::vector<GF27>& syms, Tile2D tile) { if (!t3hip_is_ready()) t3hip_init(0); t3hip_interleave2d(syms.data(), syms.size(), tile.w, tile.h, 0); }
@@ -365,18 +400,25 @@ inline bool decode_frame(const std::vector<Word27>& in, std::vector<PixelYCbCrQu
 }
 
 // ---- self-tests with the reference's inputs (OLD:1172-1230) ------------------------------------------------------------
-// The reference's own versions fail; these run the same inputs through FIXED mode, where they pass.
-inline bool selftest_rs_unit() {   // OLD:1172-1207, same data pattern, error positions and values (std::mt19937 rng(1)); FIXED arithmetic
-    if (!t3::ensure_device()) return false;
+// The reference's own versions return false / false (its encode_block is not an RS encoder and its framings disagree).
+// Default: the same inputs through FIXED arithmetic, where both pass.  Compile with -DT3_SELFTEST_REFERENCE_ARITHMETIC to run them
+// exactly as the reference does (COMPAT arithmetic, the reference's statements in the reference's order): both then return the
+// reference's verdicts, false / false (tests/golden/ref_vectors.json "selftests").
+#ifdef T3_SELFTEST_REFERENCE_ARITHMETIC
+static constexpr uint8_t T3_SELFTEST_MODE = T3_MODE_COMPAT;
+#else
+static constexpr uint8_t T3_SELFTEST_MODE = T3_MODE_FIXED;
+#endif
+inline bool selftest_rs_unit() {   // OLD:1172-1207: same data pattern, error positions and values (std::mt19937 rng(1)); host arithmetic only
     GF27Context gf; gf.init();
     std::mt19937 rng(1);
     for (ProfileID pid : {ProfileID::P1_RS26_24, ProfileID::P2_RS26_22, ProfileID::P3_RS26_20, ProfileID::P4_RS26_18}) {
-        RSCodec rs; rs.mode = T3_MODE_FIXED; rs.init(&gf, rs_params_for(pid));
+        RSCodec rs; rs.mode = T3_SELFTEST_MODE; rs.init(&gf, rs_params_for(pid));
         const int n = rs.params.n, k = rs.params.k, t = (n - k) / 2;
         std::vector<GF27> data((size_t)k);
         for (int i = 0; i < k; ++i) data[(size_t)i] = (GF27)((i * 5 + 7) % 27);
         std::vector<GF27> code((size_t)n);
-        if (!rs.encode_block(data.data(), code.data())) return false;
+        rs.encode_block(data.data(), code.data());
         std::uniform_int_distribution<int> pos(0, n - 1), val(1, 26);
         std::vector<int> used;
         for (int e = 0; e < t; ++e) {
@@ -391,12 +433,15 @@ inline bool selftest_rs_unit() {   // OLD:1172-1207, same data pattern, error po
     }
     return true;
 }
-inline bool selftest_api_roundtrip() {
+inline bool selftest_api_roundtrip() {   // OLD:1208-1230
     std::vector<PixelYCbCrQuant> px(64);
     for (size_t i = 0; i < px.size(); ++i) { px[i].Yq = (uint16_t)(i * 7 % 243); px[i].Cbq = (int16_t)((int)(i * 3 % 81) - 40); px[i].Crq = (int16_t)((int)(i * 5 % 81) - 40); }
     std::vector<Word27> raw, coded, back;
-    EncoderContext e; e.cfg.profile = ProfileID::P2_RS26_22; e.cfg.mode = T3_MODE_FIXED; uep_luma_priority(e.cfg.uep);
-    DecoderContext d; d.cfg_last_seen.mode = T3_MODE_FIXED;
-    if (!encode_raw_pixels_to_words(px, raw) || !encode_profile_from_raw(raw, coded, e) || !decode_profile_to_raw(coded, back, d)) return false;
-    return back.size() == raw.size() && std::memcmp(back.data(), raw.data(), raw.size() * 9) == 0;
+    if (!encode_raw_pixels_to_words(px, raw)) return false;
+    EncoderContext e; e.cfg.profile = ProfileID::P2_RS26_22; e.cfg.mode = T3_SELFTEST_MODE; uep_luma_priority(e.cfg.uep);
+    if (!encode_profile_from_raw(raw, coded, e)) return false;
+    DecoderContext d; d.cfg_last_seen.mode = T3_SELFTEST_MODE;
+    if (!decode_profile_to_raw(coded, back, d)) return false;
+    const size_t L = std::min(raw.size(), back.size());               // the reference compares the common prefix (OLD:1226-1228)
+    return std::memcmp(back.data(), raw.data(), L * 9) == 0;
 }

@@ -566,6 +566,11 @@ COMM_ID_BYTES = 128
 PAD_FRAME_IDX = 2**64 - 1
 
 
+def comm_available():
+    """True when RCCL can be bound in this process (t3hip_comm_available: dlopen only -- no collective, no device call)."""
+    return lib().t3hip_comm_available() == 0
+
+
 def comm_unique_id():
     """Rank 0: the 128-byte rendezvous id of a new RCCL communicator (ncclGetUniqueId); hand it to the other ranks."""
     buf = (C.c_uint8 * COMM_ID_BYTES)()

@@ -39,6 +39,8 @@ struct Ctx {
     // launch -> download -> synchronise sequence (two caller threads otherwise interleave on the stream and overwrite, or free,
     // each other's scratch).  Recursive: some of them are built from others.
     std::recursive_mutex host_mu;
+    std::mutex tab_mu, qt_mu;                             // lazily built device tables of the decode / RGB halves (per context: contexts share no lock)
+    std::recursive_mutex mail_mu;                         // pinned host mailboxes + CRC accumulator of the synchronous entry points
     void* slot[48] = {};                                  // device / pinned objects of the other translation units (api_slot), freed by their owners
 };
 // One context per GPU.  t3hip_init creates the process default; t3hip_create more (one per device for a host that drives a whole
@@ -481,7 +483,18 @@ extern "C" {
 
 int t3hip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
+static int ctx_init_in(Ctx* c, int device);
+static void ctx_teardown(Ctx* c);
+// Builds `c` on `device`.  The calling thread's current context is `c` for the whole of it, so a HIP error is recorded in `c` (and
+// copied to the null context for t3hip_last_hip_error after a failed create); what a failed build had already allocated is released.
 static int ctx_init(Ctx* c, int device) {
+    Ctx* const prev = tl_cur; tl_cur = c;
+    const int rc = ctx_init_in(c, device);
+    tl_cur = prev;
+    if (rc) { const std::string err = c->hip_err; ctx_teardown(c); g_null.hip_err = err; c->hip_err = err; }
+    return rc;
+}
+static int ctx_init_in(Ctx* c, int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return T3_E_NODEVICE;
     HIPCHK(hipSetDevice(device));
@@ -498,26 +511,26 @@ static int ctx_init(Ctx* c, int device) {
         HIPCHK(hipMemcpy(c->d_P[i][m], P, sizeof P, hipMemcpyHostToDevice));
     }
     HIPCHK(hipMalloc((void**)&c->d_flag, 64));
-    Ctx* const prev = tl_cur; tl_cur = c;                 // the decode half builds its tables into the context it finds current
-    const int rc = t3::decode_init(c->d_tab);
-    tl_cur = prev;
+    c->dev = device;
+    const int rc = t3::decode_init(c->d_tab);             // the decode half builds its tables into the context it finds current (= c)
     if (rc) return rc;
-    c->dev = device; c->ready = true;
+    c->ready = true;
     return T3_OK;
 }
-static void ctx_teardown(Ctx* c) {
+static void ctx_teardown(Ctx* c) {                       // also of a partly built context (ctx_init failed): every member is null-safe
     Ctx* const prev = tl_cur; tl_cur = c;
-    (void)hipSetDevice(c->dev);
-    (void)hipDeviceSynchronize();
+    if (c->dev >= 0) { (void)hipSetDevice(c->dev); (void)hipDeviceSynchronize(); }
     for (auto& kv : c->luts) { (void)hipFree(kv.second.d_img); if (kv.second.d_afrag) (void)hipFree(kv.second.d_afrag); }
     c->luts.clear();
     for (auto& kv : c->sbuf) if (kv.second.first) (void)hipFree(kv.second.first);
     c->sbuf.clear();
-    for (int i = 0; i < 4; ++i) { if (c->buf[i]) (void)hipFree(c->buf[i]); c->buf[i] = nullptr; c->cap[i] = 0; for (int m = 0; m < 2; ++m) { (void)hipFree(c->d_P[i][m]); c->d_P[i][m] = nullptr; } }
+    for (int i = 0; i < 4; ++i) { if (c->buf[i]) (void)hipFree(c->buf[i]); c->buf[i] = nullptr; c->cap[i] = 0; for (int m = 0; m < 2; ++m) { if (c->d_P[i][m]) (void)hipFree(c->d_P[i][m]); c->d_P[i][m] = nullptr; } }
     t3::decode_shutdown();                                // frees what the other translation units keep in this context's slots
+    if (c->slot[47]) (void)hipFree(c->slot[47]);          // chroma quantiser table of the fused RGB front end (rgb_quant_table)
     for (void*& p : c->slot) p = nullptr;
     if (c->d_ctr) { (void)hipFree(c->d_ctr); c->d_ctr = nullptr; } c->ctr_slot.clear();
-    (void)hipFree(c->d_tab); (void)hipFree(c->d_flag); (void)hipStreamDestroy(c->stream);
+    if (c->d_tab) (void)hipFree(c->d_tab); if (c->d_flag) (void)hipFree(c->d_flag); if (c->stream) (void)hipStreamDestroy(c->stream);
+    c->d_tab = nullptr; c->d_flag = nullptr; c->stream = nullptr;
     c->ready = false; c->dev = -1;
     tl_cur = prev == c ? nullptr : prev;
 }
@@ -528,7 +541,7 @@ int t3hip_init(int device) {
     if (g_def && g_def->ready) return g_def->dev == device ? T3_OK : T3_E_ARG;      // the default context stays on its device: t3hip_shutdown first, or t3hip_create
     if (!g_def) g_def = new Ctx();
     const int rc = ctx_init(g_def, device);
-    if (rc) { g_null.hip_err = g_def->hip_err; delete g_def; g_def = nullptr; }
+    if (rc) { delete g_def; g_def = nullptr; }
     return rc;
 }
 
@@ -548,7 +561,7 @@ int t3hip_create(int device, t3hip_ctx** out) {
     Ctx* c = new Ctx();
     const int rc = ctx_init(c, device);
     if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
-    if (rc) { g_null.hip_err = c->hip_err; delete c; return rc; }
+    if (rc) { delete c; return rc; }
     *out = (t3hip_ctx*)c;
     return T3_OK;
 }
@@ -707,5 +720,8 @@ RsTables* api_tables() { return g.d_tab; }
 int api_n_cu() { return g.n_cu; }
 int api_device() { return g.dev; }
 std::recursive_mutex& api_host_mutex() { return g.host_mu; }
+std::mutex& api_tab_mutex() { return g.tab_mu; }
+std::mutex& api_qt_mutex() { return g.qt_mu; }
+std::recursive_mutex& api_mail_mutex() { return g.mail_mu; }
 void*& api_slot(int id) { return g.slot[id]; }
 }  // namespace t3

@@ -41,6 +41,32 @@ int t3hip_crc12(const uint8_t* trits, uint64_t n, uint8_t out12[12]) {
     crc12(trits, (int)n, out12); return T3_OK;
 }
 
+// One block on the host: what a caller that loops RSCodec::encode_block / decode_block block by block needs (the reference's
+// self-test OLD:1172-1207, its header RS OLD:1142-1158) -- 26 bytes are control data, like the header codec; the parity
+// matrix and the decoder are the ones the kernels are built from (t3_host.cpp, t3_rs_core.h).
+int t3hip_rs_encode_block_host(int k, int mode, const uint8_t* data_k, uint8_t* code26) {
+    if (!valid_k(k) || mode < 0 || mode > 1 || !data_k || !code26) return T3_E_ARG;
+    static uint8_t P[2][4][24 * 8]; static std::once_flag once;
+    std::call_once(once, [] { for (int m = 0; m < 2; ++m) for (int q = 0; q < 4; ++q) rs_parity_matrix(24 - 2 * q, m, P[m][q]); });
+    const int r = 26 - k; const uint8_t* Pk = P[mode][(24 - k) / 2]; const Field& F = field();
+    uint8_t par[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < k; ++i) {
+        const uint8_t di = data_k[i] % 27u; code26[i] = data_k[i];
+        for (int j = 0; j < r; ++j) par[j] = F.t.add[par[j] * 27 + F.t.mul[di * 27 + Pk[i * r + j]]];
+    }
+    for (int j = 0; j < r; ++j) code26[k + j] = par[j];
+    return T3_OK;
+}
+int t3hip_rs_decode_block_host(int k, int mode, uint8_t* code26, uint8_t* data_k) {
+    if (!valid_k(k) || mode < 0 || mode > 1 || !code26 || !data_k) return T3_E_ARG;
+    uint8_t c[26];
+    for (int i = 0; i < 26; ++i) c[i] = code26[i] % 27u;
+    const bool good = rs_decode_host(k, c, mode == T3_MODE_FIXED);
+    memcpy(code26, c, 26);                                                 // corrected (or partially modified) in place, like inout_n
+    if (good) memcpy(data_k, c, (size_t)k);                                // out_k only on success (OLD:564,660)
+    return good ? 1 : 0;
+}
+
 int t3hip_rs_encode_blocks(int k, int mode, const uint8_t* data_k, uint64_t n_blocks, uint8_t* code26) {
     if (!api_ready()) return T3_E_NODEVICE;
     if (!valid_k(k) || mode < 0 || mode > 1) return T3_E_ARG;

@@ -18,7 +18,7 @@
 
 namespace t3 {
 int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr);
-int api_fail_hip(hipError_t e, const char* what); uint32_t* api_flag(); RsTables* api_tables(); int api_n_cu(); int api_device(); std::recursive_mutex& api_host_mutex();
+int api_fail_hip(hipError_t e, const char* what); uint32_t* api_flag(); RsTables* api_tables(); int api_n_cu(); int api_device(); std::recursive_mutex& api_host_mutex(); std::mutex& api_tab_mutex(); std::recursive_mutex& api_mail_mutex();
 void*& api_slot(int id);          // per-context object slots (t3_api.cpp): this file owns 0..31
 }  // namespace t3
 using namespace t3;
@@ -51,8 +51,10 @@ int k_index(int k) { return k == 24 ? 0 : k == 22 ? 1 : k == 20 ? 2 : k == 18 ? 
 DevDiv to_dev(FastDiv f) { return DevDiv{f.mul, f.sh, f.d}; }
 
 // Fused FIXED decode (t3_decode_fused.hip): uniform k, 1-D, no beacon.  Returns T3_OK after launching, or 1 if not applicable.
-std::mutex g_tab_mu;   // the lazily built device tables below are shared by every caller thread
-std::recursive_mutex g_mail_mu;   // ... and so are the pinned host mailboxes of the synchronous entry points
+// The lazily built device tables below are shared by every caller thread of a context, and so are the pinned host mailboxes of the
+// synchronous entry points: both locks live in the context (api_tab_mutex / api_mail_mutex), two contexts never share one.
+#define g_tab_mu api_tab_mutex()
+#define g_mail_mu api_mail_mutex()
 
 // device tables of one code (syndrome LUT, root masks) and the multiply-accumulate table, built on first use
 int ensure_fx_tables(int k) {
@@ -565,7 +567,7 @@ static int launch_crc(const uint8_t* d_data, uint64_t n_bytes, uint32_t* acc, hi
     HIPCHK(hipMemsetAsync(acc, 0, 8, s));
     uint64_t done = 0;
     static const int rpw_env = [] { const char* e = getenv("T3HIP_CRC_ROUNDS_PER_WAVE"); return e ? atoi(e) : 0; }();
-    if (((uintptr_t)d_data & 15u) == 0 && n_bytes >= 64 * 2048 && (n_bytes >> 11) < (1ull << 32) && getenv("T3HIP_CRC_TABLES") == nullptr) {
+    if (((uintptr_t)d_data & 15u) == 0 && n_bytes >= 64 * 2048 && (n_bytes >> 11) < (1ull << 32) && n_bytes < (1ull << kCrcPows) && getenv("T3HIP_CRC_TABLES") == nullptr) {   // (the epilogue walks the distance bit by bit over kCrcPows operators)
         CrcMArgs m; memset(&m, 0, sizeof m);
         m.data = d_data; m.n_bytes = n_bytes; m.n_rounds = (uint32_t)(n_bytes >> 11);
         // Four-wave workgroups, two waves per SIMD over the whole chip: a wave needs ~100 VGPRs (the bit matrix), which is what a

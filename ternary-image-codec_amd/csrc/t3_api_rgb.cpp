@@ -10,7 +10,7 @@
 #include "t3_rgb.h"
 
 namespace t3 {
-int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr); std::recursive_mutex& api_host_mutex();
+int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr); std::recursive_mutex& api_host_mutex(); std::mutex& api_qt_mutex();
 int api_fail_hip(hipError_t e, const char* what);
 void*& api_slot(int id);
 int api_encode_rgb_fused(const void* d_rgb, uint64_t n_px, const t3_cfg* cfg, void* d_out, uint64_t cap, uint64_t* n_out, hipStream_t s);
@@ -21,7 +21,7 @@ using namespace t3;
 
 namespace {
 #define d_qt (*(QuantTables**)&api_slot(32))     // per-context slot (t3_api.cpp)
-std::mutex g_qt_mu;
+#define g_qt_mu api_qt_mutex()                   // per context, like the table it guards
 int tables(const QuantTables** out) {
     std::lock_guard<std::mutex> lk(g_qt_mu);
     if (!d_qt) {

@@ -6,6 +6,7 @@
 // without RCCL, and shares the copy a host process has already mapped (PyTorch-ROCm ships one under the same SONAME).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -27,13 +28,15 @@ struct Rccl {
 };
 Rccl R;
 std::mutex mu;
-std::string last_err;
+thread_local std::string last_err;     // per thread: one context per thread may fail or read at the same time
 
 int fail(const std::string& what) { last_err = what; return T3_E_COMM; }
 
 int bind() {
     std::lock_guard<std::mutex> lk(mu);
     if (R.so) return T3_OK;
+    const char* off = getenv("T3HIP_COMM_DISABLE");                  // tests: behave as on a box without RCCL
+    if (off && off[0] == '1') return fail("RCCL disabled by T3HIP_COMM_DISABLE");
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* so = nullptr;
     for (const char* n : names) { so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (so) break; }
@@ -58,6 +61,8 @@ struct t3_comm { ncclComm_t comm; int world, rank, device; };
 extern "C" {
 
 const char* t3hip_comm_last_error(void) { return last_err.c_str(); }
+
+int t3hip_comm_available(void) { return bind(); }
 
 int t3hip_comm_unique_id(uint8_t id[T3_COMM_ID_BYTES]) {
     static_assert(T3_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
@@ -95,6 +100,7 @@ int t3hip_comm_rank(const t3_comm* c) { return c ? c->rank : -1; }
 int t3hip_index_allgather(t3_comm* c, const t3_frame_record* d_local, uint64_t n_local, t3_frame_record* d_all, void* stream) {
     if (!c || (n_local && (!d_local || !d_all))) return T3_E_ARG;
     if (!n_local) return T3_OK;
+    if (!R.AllGather) return fail("t3hip_index_allgather: RCCL not bound");       // (a t3_comm cannot exist without it)
     const ncclResult_t r = R.AllGather(d_local, d_all, (size_t)n_local * sizeof(t3_frame_record), ncclUint8, c->comm, (hipStream_t)stream);
     return r == ncclSuccess ? T3_OK : nccl_fail(r, "ncclAllGather");
 }

@@ -1,5 +1,5 @@
-// t3_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the Word27 path.  No MFMA anywhere: the
-// work is byte/trit permutation plus GF(3)-linear small-field arithmetic and the bound is HBM.
+// t3_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the Word27 encode path.  Byte/trit permutation plus GF(3)-linear
+// small-field arithmetic; the RS parity of the frame kernels runs on v_mfma_i32_32x32x32_i8 (phase2_mfma below); bound: HBM.
 //
 //   K1 pack_pixels_kernel     pixels -> raw Word27                       (encode_raw_pixels_to_words OLD:723-734)
 //   K5 unpack_words_kernel    raw Word27 -> pixels                       (decode_raw_words_to_pixels OLD:735-747)

@@ -11,7 +11,7 @@ carries the 128-byte rendezvous id between the ranks, over whatever process grou
 (torch.distributed here).  `gather_records_torch` is the CPU rehearsal of the same control flow over gloo (tests only)."""
 import numpy as np
 
-from . import Comm, FRAME_RECORD_BYTES, PAD_FRAME_IDX, comm_unique_id, index_assemble
+from . import Comm, FRAME_RECORD_BYTES, PAD_FRAME_IDX, comm_available, comm_unique_id, index_assemble
 
 
 def frames_of_rank(n_frames, rank, world):
@@ -20,16 +20,27 @@ def frames_of_rank(n_frames, rank, world):
 
 
 def make_comm(group=None):
-    """RCCL communicator over the ranks of a torch.distributed group: rank 0 draws the unique id, a CPU broadcast carries it
-    (the group needs a CPU-capable backend, e.g. "cpu:gloo,cuda:nccl").  Call after t3.init(local_device)."""
+    """RCCL communicator over the ranks of a torch.distributed group, or None -- on EVERY rank -- when any rank cannot have one.
+    The rendezvous cannot strand a rank: (1) every rank probes the binding locally (t3hip_comm_available: dlopen only, no
+    collective), (2) the ranks agree with an all-reduce(MIN) on the group's CPU backend, (3) rank 0 draws the unique id only if all
+    ranks are able, and the broadcast of (status byte, id) happens on every path, so the collectives match whatever failed,
+    (4) only then does anyone enter ncclCommInitRank.  The group needs a CPU-capable backend (e.g. "cpu:gloo,cuda:nccl").  Call
+    after t3.init(local_device)."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    box = torch.zeros(128, dtype=torch.uint8)
-    if rank == 0:
-        box.copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8))
+    able = torch.tensor([1 if comm_available() else 0])
+    dist.all_reduce(able, op=dist.ReduceOp.MIN, group=group)
+    box = torch.zeros(129, dtype=torch.uint8)
+    if rank == 0 and int(able.item()) == 1:
+        try:
+            box[1:].copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8)); box[0] = 1
+        except Exception:   # noqa: BLE001  (ncclGetUniqueId failed: the others learn it from the status byte)
+            box[0] = 0
     dist.broadcast(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    return Comm(bytes(box.numpy().tobytes()), world, rank)
+    if int(box[0].item()) != 1:
+        return None
+    return Comm(bytes(box[1:].numpy().tobytes()), world, rank)
 
 
 def gather_records(comm, local_records, stream=None):

@@ -85,3 +85,46 @@ def test_round_robin_shard():
             seen = sorted(f for r in range(world) for f in sf.frames_of_rank(n, r, world))
             assert seen == list(range(n))
     assert sf.frames_of_rank(64, 3, 8) == [3, 11, 19, 27, 35, 43, 51, 59]           # BASELINE config 4: 8 frames per GPU
+
+
+def _comm_worker(rank, world, port, q, disable_on):
+    """make_comm with RCCL unbindable on the ranks in `disable_on`: every rank must come back with None, no rank may hang."""
+    if rank in disable_on:
+        os.environ["T3HIP_COMM_DISABLE"] = "1"
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    t3 = ge.load_package()
+    sf = __import__("ternary_image_codec_amd.superframe", fromlist=["x"])
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    able = t3.comm_available()
+    try:
+        comm = sf.make_comm(); res = "none" if comm is None else "comm"
+    except Exception as e:   # noqa: BLE001  (no device in this container: t3hip_comm_create refuses, on every rank alike)
+        res = "raise:" + type(e).__name__
+    t = torch.tensor([rank + 1]); dist.all_reduce(t)                 # the collectives still line up afterwards
+    q.put((rank, able, res, int(t.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("disable_on", [(0, 1), (1,), (0,)])
+def test_comm_rendezvous_cannot_strand_a_rank(t3, disable_on):
+    """a rank that cannot bind RCCL (all ranks of a node without librccl, or one rank only) must not leave the others in a
+    mismatched collective or inside ncclCommInitRank: make_comm probes locally, agrees with an all-reduce, always broadcasts, and
+    returns None on EVERY rank -- bench.py then reports the torch.distributed fallback in config.exchange."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q, disable_on)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[0] for g in got] == [0, 1] and all(g[3] == 3 for g in got)
+    for r, able, res, _ in got:
+        assert able == (r not in disable_on)
+        assert res == "none"

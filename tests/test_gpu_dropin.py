@@ -20,10 +20,10 @@ def build_demo(tmp):
     return exe
 
 
-def build_refnames(tmp, src=None):
-    exe = os.path.join(tmp, "refnames_demo" if src is None else "ref_main_bare")
+def build_refnames(tmp, src=None, extra=()):
+    exe = os.path.join(tmp, ("refnames_demo" if src is None else "ref_main_bare") + ("_x" if extra else ""))
     lib = os.path.join(ROOT, "ternary-image-codec_amd")
-    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include", "compat"), "-I" + os.path.join(ROOT, "include"),
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", *extra, "-I" + os.path.join(ROOT, "include", "compat"), "-I" + os.path.join(ROOT, "include"),
                     src or os.path.join(ROOT, "tests", "cpp", "refnames_demo.cpp"), "-L" + lib, "-lt3hip", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
     return exe
 
@@ -31,8 +31,9 @@ def build_refnames(tmp, src=None):
 def test_reference_caller_compiles_against_dropin_header(t3, tmp_path):
     """The reference's own self-test runner (old/src/main_bare.cpp: includes "ternary_image_codec_v6_min.hpp", calls selftest_rs_unit
     and selftest_api_roundtrip) compiles UNCHANGED against include/compat + include/ternary_codec_v6.hpp with g++ alone, and so
-    does tests/cpp/refnames_demo.cpp, which touches every other public name of the path.  Without a GPU both answer false /
-    T3_E_NODEVICE (no fallback).  The reference source is read where it lies, only in this container."""
+    does tests/cpp/refnames_demo.cpp, which touches every other public name of the path.  Without a GPU the frame-level self-test
+    answers false / T3_E_NODEVICE (no fallback); selftest_rs_unit walks single blocks, which are host arithmetic, and passes.  The
+    reference source is read where it lies, only in this container."""
     import torch
     exe2 = build_refnames(str(tmp_path))
     ref_main = "/root/reference/old/src/main_bare.cpp"
@@ -41,9 +42,10 @@ def test_reference_caller_compiles_against_dropin_header(t3, tmp_path):
         pytest.skip("a GPU is present: covered by the gpu test")
     if exe:
         r = subprocess.run([exe], capture_output=True, text=True)
-        assert r.returncode == 1 and r.stdout.strip() == "RS:FAIL API:FAIL"          # no device: every call returns false
+        assert r.returncode == 1 and r.stdout.strip() == "RS:OK API:FAIL"            # no device: every frame-level call returns false
     out = json.loads(subprocess.run([exe2], check=True, capture_output=True, text=True).stdout)
-    assert out["selftest_rs_unit"] == 0 and out["selftest_api_roundtrip"] == 0
+    assert out["selftest_rs_unit"] == 1 and out["selftest_api_roundtrip"] == 0
+    assert out["word"] == [21, 5, 13, 7, 26, 1, 17, 20, 6] and out["unpack_equal"] == 1      # pack_two_pixels: host arithmetic
     # the host-side control arithmetic needs no device: field, generator polynomials, scrambler, beacon symbol, CRC-12
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_vectors.json")))
     assert out["primitive"] == 3 and out["order3"] == 26 and out["scr_back"] == 1 and out["tr2i"] == 200
@@ -99,6 +101,17 @@ def test_reference_names_on_device(gpu, orc, tmp_path):
     assert out["word"] == [21, 5, 13, 7, 26, 1, 17, 20, 6] and out["unpack_equal"] == 1 and out["tr2i"] == 200
 
 
+@pytest.mark.gpu
+def test_selftests_in_reference_arithmetic(gpu, tmp_path):
+    """-DT3_SELFTEST_REFERENCE_ARITHMETIC: selftest_rs_unit / selftest_api_roundtrip run the reference's statements in COMPAT arithmetic
+    and return the reference's own verdicts (golden "selftests", captured from the reference build: false, false) -- identical
+    results on the same inputs for these two entry points as well; the default build keeps FIXED arithmetic, where they pass."""
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_vectors.json")))
+    out = json.loads(subprocess.run([build_refnames(str(tmp_path), extra=("-DT3_SELFTEST_REFERENCE_ARITHMETIC",))], check=True, capture_output=True, text=True).stdout)
+    assert [bool(out["selftest_rs_unit"]), bool(out["selftest_api_roundtrip"])] == g["selftests"] == [False, False]
+    assert out["status"] in (-5, -6)                                              # T3_E_HEADER / T3_E_RS: the reference's decoder rejects its encoder's stream
+
+
 def test_dropin_header_compiles_and_refuses_without_gpu(t3, tmp_path):
     """CPU: the header builds with g++ alone; with no device every call returns false with T3_E_NODEVICE (no fallback)."""
     import torch
@@ -148,7 +161,8 @@ def test_bench_self_launch_cpu():
     env["T3_BENCH_RANK_PROBE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = sorted(l for l in r.stdout.splitlines() if l.startswith("probe rank"))
+    import re
+    lines = sorted(re.findall(r"probe rank \d of \d sum \d", r.stdout))                # (the two ranks write to one pipe)
     assert lines == ["probe rank 0 of 2 sum 3", "probe rank 1 of 2 sum 3"]
 
 

@@ -201,3 +201,60 @@ def test_mfma_encode_tables_reproduce_the_parity_matrix(t3, orc, k, mode):
             e = int(T[v][d]); tr = [d % 3, (d // 3) % 3, d // 9]
             assert [_sb((e >> (8 * q)) & 0xFF) for q in range(3)] == [(-1 if t == 2 else t) for t in tr]
             assert e >> 24 == sum(((tr[t] + v) % 3) * 3 ** t for t in range(3))
+
+
+def _build_hostnames(tmp, extra=()):
+    import subprocess
+    exe = os.path.join(tmp, "hostnames_demo" + ("_ref" if extra else ""))
+    lib = os.path.join(ROOT, "ternary-image-codec_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", *extra, "-I" + os.path.join(ROOT, "include", "compat"), "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "hostnames_demo.cpp"), "-L" + lib, "-lt3hip", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    return exe
+
+
+def test_device_free_reference_names(built, tmp_path):
+    """pack_two_pixels / unpack_two_pixels are host integer arithmetic in the drop-in header (OLD:693-722): golden lcg5 / quirk vectors
+    captured from the reference, without a device.  RSCodec one block at a time and the context members the reference's callers can
+    reach (OLD:885-916) work on the host too; selftest_rs_unit returns true in FIXED arithmetic and, compiled with
+    -DT3_SELFTEST_REFERENCE_ARITHMETIC, the reference's own verdict (golden "selftests"[0] = false)."""
+    import subprocess
+    orc = ol.oracle()
+    P = GOLD["pack"]
+    px = P["lcg5_px"] + [[0, 0, 0]] + P["quirk_px"]                                  # (odd count: the reference pads a zero pixel, OLD:730)
+    words = P["lcg5_words"] + P["quirk_words"]
+    stdin = "%d %s %d %s\n" % (len(px), " ".join(str(v) for p in px for v in p), len(words) // 9, " ".join(str(v) for v in words))
+    want_px = [v for p in (P["lcg5_px"] + [[0, 0, 0]] + P["quirk_unpacked"]) for v in p]
+    data = np.array([(i * 5 + 7) % 27 for i in range(20)], np.uint8)
+    for extra, verdict in (((), 1), (("-DT3_SELFTEST_REFERENCE_ARITHMETIC",), int(GOLD["selftests"][0]))):
+        out = json.loads(subprocess.run([_build_hostnames(str(tmp_path), extra)], input=stdin, check=True, capture_output=True, text=True).stdout)
+        assert out["words"] == words and out["pixels"] == want_px
+        assert out["compat_code"] == [int(x) for x in orc.rs_encode_blocks(20, data, 0)[0]]
+        assert out["fixed_recovered"] == 1 and out["hdr_k"] == 18 and out["p1_k"] == 24 and out["p4_g"] == 9 and out["own_gf"] == 1
+        assert out["gf_mul"] == int(orc.gf_tables()["mul"][5 * 27 + 7])
+        assert out["selftest_rs_unit"] == verdict and out["reference_arithmetic"] == (1 if extra else 0)
+
+
+def test_host_block_codec_matches_oracle(built):
+    """t3hip_rs_encode_block_host / t3hip_rs_decode_block_host (what RSCodec binds) against the oracle's block codec, which is pinned to
+    the reference: every k, both arithmetics, 0..t+1 symbol errors, verdicts and bytes."""
+    orc = ol.oracle(); lib = built.lib()
+    lib.t3hip_rs_encode_block_host.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.t3hip_rs_decode_block_host.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    for k in (24, 22, 20, 18):
+        t = (26 - k) // 2
+        for mode in (0, 1):
+            for trial in range(40):
+                data = rng.integers(0, 27, k, dtype=np.uint8)
+                code = np.zeros(26, np.uint8)
+                assert lib.t3hip_rs_encode_block_host(k, mode, data.ctypes.data, code.ctypes.data) == 0
+                assert np.array_equal(code, orc.rs_encode_blocks(k, data, mode)[0])
+                bad = code.copy()
+                for p in rng.choice(26, trial % (t + 2), replace=False):
+                    bad[p] = (bad[p] + int(rng.integers(1, 27))) % 27
+                cw, dk, okv = orc.rs_decode_blocks(k, bad, mode)
+                mine = bad.copy(); outk = np.full(k, 77, np.uint8)
+                rc = lib.t3hip_rs_decode_block_host(k, mode, mine.ctypes.data, outk.ctypes.data)
+                assert rc == int(okv[0]) and np.array_equal(mine, cw[0])
+                assert np.array_equal(outk, dk[0]) if rc else np.all(outk == 77)
+    assert lib.t3hip_rs_encode_block_host(21, 0, data.ctypes.data, code.ctypes.data) == -3
