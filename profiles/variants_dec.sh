@@ -1,7 +1,10 @@
 #!/bin/bash
-# run the full bench step (encode + decode + record) against every libt3hip_*.so variant present and print decode_ms
+# decode-only loop (profiles/dec_loop.py: streaming entry, exactness checked) against the product library and every libt3hip_*.so
+# variant present (profiles/build_variant.sh): clean stream and the bench workload (0..3 errors in every block)
 cd "$(dirname "$0")/.."
 for so in ternary-image-codec_amd/libt3hip.so ternary-image-codec_amd/libt3hip_*.so; do
   echo "== $so"
-  T3HIP_LIB=$PWD/$so python bench.py --serial --no-cpu-baseline --no-verify --steps 10 --warmup 3 2>&1 | grep -E "stamps|decode_ms" | sed 's/.*"encode_ms": \([0-9.]*\), "decode_ms": \([0-9.]*\).*/encode_ms \1 decode_ms \2/'
+  for mode in errors clean; do
+    T3HIP_LIB=$PWD/$so timeout -k 10 120 python profiles/dec_loop.py $mode 50 300 ${1:-c2} 2>&1 | grep -E "dec_loop|stamps|Error|error" | tail -3
+  done
 done

@@ -31,7 +31,7 @@ struct Ctx {
     std::map<uint32_t, LutImage> luts;                  // key = kmask | mode << 8
     void* buf[4] = {nullptr, nullptr, nullptr, nullptr}; size_t cap[4] = {0, 0, 0, 0};   // grow-only device scratch (slots 0, 1: host-buffer entry points)
     std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> sbuf;              // slots 2, 3: intermediates of the *_dev entry points, one set per caller stream
-    uint32_t* d_ctr = nullptr; std::map<hipStream_t, uint32_t> ctr_slot;   // tile-ticket counters, one pair per stream in use
+    uint32_t* d_ctr = nullptr; std::map<std::pair<hipStream_t, int>, uint32_t> ctr_slot;   // tile-ticket counters, one set per (stream, kernel kind) in use
     uint32_t* d_flag = nullptr;                         // failure counter for the synchronous decode entry points
     std::string hip_err;
     std::mutex mu;
@@ -57,6 +57,20 @@ int fail_hip(hipError_t e, const char* what) { g.hip_err = std::string(what) + "
 
 int k_index(int k) { return k == 24 ? 0 : k == 22 ? 1 : k == 20 ? 2 : k == 18 ? 3 : -1; }
 const int kOfIndex[4] = {24, 22, 20, 18};
+
+// Tile-ticket counters of a persistent kernel: eight class counters + a done counter, 256 B apart, zero between launches (the kernel's
+// last workgroup re-zeroes them).  One set per (stream, kernel kind: 0 encoder, 1 decoder): launches on one stream are ordered, streams
+// are not.  nullptr (the kernels then stride statically): hipStreamPerThread (one handle value, a different real stream per thread), no
+// slot left, or the allocation failed.
+uint32_t* ticket_counters(hipStream_t s, int kind) {                  // caller holds g.mu (the encoder's launch path does)
+    constexpr uint32_t kSlots = 64, kSlotWords = 64 * 9;
+    if (s == hipStreamPerThread) return nullptr;
+    if (!g.d_ctr) { if (hipMalloc((void**)&g.d_ctr, kSlots * kSlotWords * 4) != hipSuccess) { g.d_ctr = nullptr; return nullptr; } if (hipMemset(g.d_ctr, 0, kSlots * kSlotWords * 4) != hipSuccess) return nullptr; }
+    const auto key = std::make_pair(s, kind);
+    auto sl = g.ctr_slot.find(key);
+    if (sl == g.ctr_slot.end() && g.ctr_slot.size() < kSlots) sl = g.ctr_slot.emplace(key, (uint32_t)g.ctr_slot.size()).first;
+    return sl == g.ctr_slot.end() ? nullptr : g.d_ctr + kSlotWords * sl->second;
+}
 
 int scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr) {
     if (slot >= 2) {                                     // per stream: two streams may have frames in flight at the same time
@@ -298,15 +312,9 @@ int launch_fn(const void* fn, const EncLaunch& e, hipStream_t s) {
     HIPCHK(hipMemsetAsync(d_dbg, 0, 16 * 8 * 4096, s));
     const_cast<EncLaunch&>(e).a.dbg = d_dbg;
 #endif
-    {   // dynamic tile tickets: a zeroed counter pair per stream (launches on one stream are ordered; the kernel re-zeroes it)
+    {   // dynamic tile tickets: a zeroed counter set per stream (launches on one stream are ordered; the kernel re-zeroes it)
         static const bool off = getenv("T3HIP_STATIC_TILES") != nullptr;      // measurement knob
-        bool sl_force_static = false;
-        constexpr uint32_t kSlots = 64, kSlotWords = 64 * 9;                  // 8 class counters + 1 done counter, 256 B apart
-        if (!g.d_ctr) { HIPCHK(hipMalloc((void**)&g.d_ctr, kSlots * kSlotWords * 4)); HIPCHK(hipMemset(g.d_ctr, 0, kSlots * kSlotWords * 4)); }
-        if (s == hipStreamPerThread) sl_force_static = true;                   // one handle value, a different real stream per thread: no shared ticket slot
-        auto sl = g.ctr_slot.find(s);
-        if (sl == g.ctr_slot.end() && g.ctr_slot.size() < kSlots) sl = g.ctr_slot.emplace(s, (uint32_t)g.ctr_slot.size()).first;
-        const_cast<EncLaunch&>(e).a.tile_ctr = (off || sl_force_static || sl == g.ctr_slot.end()) ? nullptr : g.d_ctr + kSlotWords * sl->second;
+        const_cast<EncLaunch&>(e).a.tile_ctr = off ? nullptr : ticket_counters(s, 0);
         const_cast<EncLaunch&>(e).a.n_classes = std::min<uint32_t>(8u, grid);
     }
     void* args[] = {(void*)&e.a};
@@ -724,4 +732,5 @@ std::mutex& api_tab_mutex() { return g.tab_mu; }
 std::mutex& api_qt_mutex() { return g.qt_mu; }
 std::recursive_mutex& api_mail_mutex() { return g.mail_mu; }
 void*& api_slot(int id) { return g.slot[id]; }
+uint32_t* api_ticket_counters(hipStream_t s, int kind) { std::lock_guard<std::mutex> lk(g.mu); return ticket_counters(s, kind); }
 }  // namespace t3

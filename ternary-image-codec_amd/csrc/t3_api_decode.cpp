@@ -18,7 +18,7 @@
 
 namespace t3 {
 int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr);
-int api_fail_hip(hipError_t e, const char* what); uint32_t* api_flag(); RsTables* api_tables(); int api_n_cu(); int api_device(); std::recursive_mutex& api_host_mutex(); std::mutex& api_tab_mutex(); std::recursive_mutex& api_mail_mutex();
+int api_fail_hip(hipError_t e, const char* what); uint32_t* api_flag(); RsTables* api_tables(); int api_n_cu(); int api_device(); std::recursive_mutex& api_host_mutex(); std::mutex& api_tab_mutex(); std::recursive_mutex& api_mail_mutex(); uint32_t* api_ticket_counters(hipStream_t s, int kind);
 void*& api_slot(int id);          // per-context object slots (t3_api.cpp): this file owns 0..31
 }  // namespace t3
 using namespace t3;
@@ -130,29 +130,37 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
     { const int rc = ensure_fx_tables(k); if (rc) return rc; }
     DecFx2Args a; memset(&a, 0, sizeof a);
     a.in = body; a.in_bytes = body_bytes; a.out = d_out; a.n_units = units; a.fail = d_fail; a.roots = d_roots[ki];
-    a.ttab = to_pixels ? d_synd_T16 : d_synd_T; a.small = d_fx2_small; a.afrag = d_synd_afrag[ki];
+    a.ttab = (to_pixels && T3_DEC_PX_TCOP == 16) ? d_synd_T16 : d_synd_T; a.small = d_fx2_small; a.afrag = d_synd_afrag[ki];
     const bool rgb = to_pixels == 2;
     if (rgb) { const int rc = rgb_dequant_tables(&a.dq); if (rc) return rc; }
-    a.k = (uint32_t)k; a.nb = 52; a.div_nb = to_dev(fastdiv(a.nb)); a.TS = 9u * 52u * (uint32_t)k; a.n_sym = (uint32_t)L.n_sym; a.hdr_syms = hdr_syms;
+    a.k = (uint32_t)k; a.nb = to_pixels ? (uint32_t)T3_DEC_PX_NB : 52u; a.div_nb = to_dev(fastdiv(a.nb)); a.TS = 9u * a.nb * (uint32_t)k; a.n_sym = (uint32_t)L.n_sym; a.hdr_syms = hdr_syms;
     uint64_t maxb = 0;
     for (int b = 0; b < 9; ++b) { a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b]; a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6); maxb = std::max<uint64_t>(maxb, L.band_blocks[b]); }
     a.n_tiles = (uint32_t)((maxb + a.nb - 1) / a.nb);
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
+    {   // body symbol i >= 2 sees cyc[(i - 2) mod 6]; a block whose first symbol has phase c0 = (i0 + 4) mod 6 sees cyc[(c0 + p) mod 6] at position p
+        uint8_t rows[7][16]; memset(rows, 0, sizeof rows);
+        for (int r = 0; r < 6; ++r) for (int q = 0; q < 13; ++q) rows[r][q] = (uint8_t)(27u * sc.cyc[(r + q) % 6]);
+        for (int q = 0; q < 13; ++q) rows[6][q] = (uint8_t)(27u * (q == 0 ? sc.pre[0] : q == 1 ? sc.pre[1] : sc.cyc[(4 + q) % 6]));   // the stream's first block: c0 = 4
+        memcpy(a.pat, rows, sizeof rows);
+    }
     const bool bcn = bcn_period != 0;
     if (bcn) { a.bcn_slot = bcn_slot; a.bcn_pb = 9u * bcn_period - 1u; a.bcn_div = to_dev(fastdiv(a.bcn_pb)); }
     a.fma = d_fma;
     const uint32_t ybytes = (a.TS + 16u + 15u) & ~15u;
     if (to_pixels) {   // [hdr][fold 512][T16 1024][FMA][A operand][Y0][Y1][Q0][Q1]
-        a.fma_off = (uint32_t)kFx2TPx + 3u * 27u * 4u * 16u;
+        a.fma_off = (uint32_t)kFx2TPx + 3u * 27u * 4u * (uint32_t)T3_DEC_PX_TCOP;
         a.af_off = a.fma_off + 19696u;
-        a.y_off = a.af_off + 3328u; a.y_stride = ybytes;
+        a.pat_off = a.af_off + 3328u;
+        a.y_off = a.pat_off + 128u; a.y_stride = ybytes;
         a.q_off = a.y_off + 2u * ybytes; a.q_stride = 10u * (uint32_t)kFx2QCap;    // 8 bytes of syndromes + 2 of item number per entry
         a.o_off = a.q_off + 2u * a.q_stride; a.dq_off = a.o_off;
         a.lds_bytes = a.o_off + (rgb ? 336u : 16u);                                 // <= 42 x 1280 B: LDS is handed out in 1280-byte units, 128 per CU (three workgroups)
     } else {           // [hdr][fold 3072][T32 3584][FMA][A operand][Y][Q][words]
         a.fma_off = (uint32_t)kFx2TSeq + 3u * 27u * 4u * 32u;
         a.af_off = a.fma_off + 19696u;
-        a.y_off = a.af_off + 3328u; a.y_stride = 0;
+        a.pat_off = a.af_off + 3328u;
+        a.y_off = a.pat_off + 128u; a.y_stride = 0;
         a.q_off = a.y_off + ybytes; a.q_stride = 0;
         a.o_off = a.q_off + 10u * 512u;
         a.lds_bytes = a.o_off + (a.TS / 26u) * 27u + 64u;
@@ -173,7 +181,7 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
     auto it = occ.find(okey);
     if (it == occ.end()) {
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        int o = 1; HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, 512, a.lds_bytes));
+        int o = 1; HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, to_pixels ? T3_DEC_PX_THREADS : 512, a.lds_bytes));
         // measured on MI355X (stamp build, workgroup start times): LDS is handed out in 1280-byte units, 128 per CU; the occupancy
         // query does not round, and a persistent grid sized one workgroup per CU too large runs its last third after the rest
         o = std::min<int>(o, (int)(128u / ((a.lds_bytes + 1279u) / 1280u)));
@@ -186,8 +194,12 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
     HIPCHK(hipMemsetAsync(d_dbg, 0, 16 * 8 * 4096, s));
     a.dbg = d_dbg;
 #endif
+    if (to_pixels) {   // dynamic tile tickets (decode_fixed_px_kernel); T3HIP_STATIC_TILES: measurement knob
+        static const bool off = getenv("T3HIP_STATIC_TILES") != nullptr;
+        a.tile_ctr = off ? nullptr : api_ticket_counters(s, 1); a.n_classes = std::min<uint32_t>(8u, grid);
+    }
     void* args[] = {(void*)&a};
-    HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(512), args, a.lds_bytes, s));
+    HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(to_pixels ? T3_DEC_PX_THREADS : 512), args, a.lds_bytes, s));
 #ifdef T3_DEC_STAMPS
     if (++calls == 8 && to_pixels) {                        // one report, after warm-up: mean cycles of waves 0 / 4 per workgroup and phase
         std::vector<uint64_t> h(16 * grid);

@@ -82,9 +82,26 @@ struct DecFxArgs {
 //                           workgroup barrier per tile.  LDS: [hdr 0][fold tables 512][T16 1024][FMA][A operand][Y0][Y1][Q0][Q1]
 //   decode_fixed_kernel     (raw words out) the phases run one after the other (sets | queue | words staged in LDS).
 //                           LDS: [hdr 0][fold tables 3072][T32 3584][FMA][A operand][Y][Q][words]
-// hdr: band rows 0..143, queue counters 160/164, consumer rendezvous 168, give-up flag 172, small byte tables 192, dummy 384..511
-constexpr int kFx2Cnt = 160, kFx2Sync = 168, kFx2Abort = 172, kFx2Small = 192;
-constexpr int kFx2ModSeq = 3072, kFx2TSeq = 3584, kFx2ModPx = 512, kFx2TPx = 1024, kFx2QCap = 256;
+// hdr: band rows 0..143, queue counters 160/164, consumer rendezvous 168, give-up flag 172, ticket slots 176/180, small byte tables 192, dummy 384..511
+constexpr int kFx2Cnt = 160, kFx2Sync = 168, kFx2Abort = 172, kFx2Next = 176, kFx2Small = 192;   // kFx2Next: two words, the ticket slot of each barrier parity
+// Geometry of the pixel kernel (decode_fixed_px_kernel): threads per workgroup (half producer, half consumer waves), bank copies of
+// its T table, blocks per band per tile, queue capacity.  Measured in round 3 (profiles/r03/notes.md): 768 threads x two workgroups per
+// CU with 32 conflict-free T copies and 78 blocks per band (-DT3_DEC_PX_THREADS=768 -DT3_DEC_PX_TCOP=32 -DT3_DEC_PX_NB=78
+// -DT3_DEC_QCAP=400) is no faster than three 512-thread workgroups: the kernel is bound by vector-instruction issue, not by LDS conflicts.
+#ifndef T3_DEC_PX_THREADS
+#define T3_DEC_PX_THREADS 512
+#endif
+#ifndef T3_DEC_PX_TCOP
+#define T3_DEC_PX_TCOP 16
+#endif
+#ifndef T3_DEC_PX_NB
+#define T3_DEC_PX_NB 52
+#endif
+#ifndef T3_DEC_QCAP
+#define T3_DEC_QCAP 256
+#endif
+constexpr int kFx2ModSeq = 3072, kFx2TSeq = 3584, kFx2ModPx = 512, kFx2TPx = 1024, kFx2QCap = T3_DEC_QCAP;
+static_assert(T3_DEC_PX_THREADS % 128 == 0 && T3_DEC_PX_THREADS <= 1024 && T3_DEC_PX_NB % 26 == 0 && 9 * T3_DEC_PX_NB <= T3_DEC_PX_THREADS && T3_DEC_PX_NB < 2048, "pixel-decoder geometry");
 struct DecFx2Args {
     const uint8_t* in; uint64_t in_bytes;      // whole coded stream
     void* out; uint64_t n_units;               // pixels or words to emit
@@ -98,6 +115,8 @@ struct DecFx2Args {
     uint32_t hdr_syms;
     uint32_t band_blocks[9]; uint64_t band_body_off[9]; uint32_t band_boff6[9];
     uint32_t cyc24, pre0, pre1;
+    uint32_t* tile_ctr; uint32_t n_classes;    // px kernel: dynamic tile tickets (n_classes counters + a done counter, 256 B apart; zero between launches); null = static stride
+    uint32_t pat[28], pat_off;                 // seven 16-byte rows: byte q of row r < 6 = 27 x scrambler state of a position of class (r + q) mod 6; row 6: the stream's first block (pre-period states in bytes 0, 1)
     uint32_t y_off, y_stride, q_off, q_stride, o_off, af_off, lds_bytes;   // px kernel: two symbol buffers / queues, y_stride / q_stride apart
     uint32_t bcn_slot, bcn_pb; DevDiv bcn_div;   // BCN kernels: a beacon symbol sits in front of body byte bcn_slot + j bcn_pb (bcn_pb = 9 period - 1 >= 17); `in` is the framed stream
     const uint8_t* dq; uint32_t dq_off;          // RGB out (row f1 fused): dequantiser tables yd[244] | cd[84] (t3_rgb.h) and their LDS offset

@@ -92,6 +92,10 @@ __device__ __forceinline__ void stage_tables(const DecFx2Args& a, const uint32_t
     for (uint32_t i = tid * 16u; i < 19696u; i += nthr * 16u) *(uint4*)(lds + a.fma_off + i) = *(const uint4*)(a.fma + i);
     for (uint32_t i = tid * 16u; i < 3072u; i += nthr * 16u) *(uint4*)(lds + a.af_off + i) = *(const uint4*)((const uint8_t*)a.afrag + i);
     if (tid < 64u) *(uint32_t*)(lds + a.af_off + 3072u + 4u * tid) = a.afrag[(3u * 64u + tid) * 4u];       // step 3: dword 0 of every lane
+    if (tid == 64u) {                                                                // scrambler pattern rows (t3_decode_fx2.h, fx2_set): constant indices only
+#pragma unroll
+        for (int i = 0; i < 28; ++i) *(uint32_t*)(lds + a.pat_off + 4 * i) = a.pat[i];
+    }
 }
 
 // D5 (pixels) for lane slot j of a tile: four triples = 52 symbols at y_off + 52 j -> 12 pixels = 72 bytes; RGB: the inverse
@@ -158,9 +162,22 @@ __device__ __forceinline__ void fx2_pixels12(const DecFx2Args& a, const uint32_t
 // pixels out: producer / consumer waves
 // ------------------------------------------------------------------------------------------------------------------
 template <int R, bool RGB, bool BCN>
-__global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_px_kernel(const DecFx2Args a) {
-    constexpr uint32_t TCOP = 16, TBASE = kFx2TPx, MT = kFx2ModPx, QCAP = kFx2QCap;
+__global__ __launch_bounds__(T3_DEC_PX_THREADS, T3_DEC_WAVES_PER_EU) void decode_fixed_px_kernel(const DecFx2Args a) {
+    constexpr uint32_t TCOP = T3_DEC_PX_TCOP, TBASE = kFx2TPx, MT = kFx2ModPx, QCAP = kFx2QCap;
+    constexpr uint32_t NW = T3_DEC_PX_THREADS / 128;                                // producer waves = consumer waves
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Tiles are handed out by tickets, as in the encoder (t3_kernels.hip): the workgroups of a CU progress at different speeds (a static
+    // stride left the slowest workgroup 20 % behind the mean: stamp build, profiles/r03/notes.md).  Workgroup w starts with tile w; every
+    // further tile is drawn from a counter -- one per class (index mod n_classes: a memory-side atomic serves ~11 ns per draw, too slow
+    // for one counter and 15 k tiles).  The id of tile k + 2 is drawn by lane 0 of wave 0 during tile k and handed to all waves through
+    // an LDS slot per barrier parity; an id >= n_tiles ends the workgroup.  a.tile_ctr == nullptr: static stride.
+    const uint32_t grid = gridDim.x;
+    const bool dyn = a.tile_ctr != nullptr;
+    const uint32_t NC = dyn ? a.n_classes : 1u, cls = blockIdx.x % NC;
+    const uint32_t wgc = (grid - cls + NC - 1u) / NC;                                // workgroups (= static first tiles) of this class
+    uint32_t* const ctr = a.tile_ctr + 64u * cls;
+    auto draw = [&]() -> uint32_t { return cls + NC * (wgc + atomicAdd(ctr, 1u)); };
+    if (tid == 0) *(uint32_t*)(lds + kFx2Next + 4u) = dyn ? draw() : blockIdx.x + grid;   // tile 1 (slot of parity 1; read behind the barrier below)
     stage_tables<TCOP, TBASE, MT>(a, tid, blockDim.x);
     if constexpr (RGB) { if (tid < 82u) *(uint32_t*)(lds + a.dq_off + 4u * tid) = ((const uint32_t*)a.dq)[tid]; }     // yd[244] | cd[84]
     __syncthreads();
@@ -168,88 +185,109 @@ __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_px_kern
     uint64_t st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime(), st_t0 = st_prev, st_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const uint8_t* body = a.in + a.hdr_syms;
-    const uint32_t n_items = 9u * a.nb, grid = gridDim.x;
-    const uint32_t n_my = blockIdx.x < a.n_tiles ? (a.n_tiles - blockIdx.x + grid - 1u) / grid : 0u;    // tiles of this workgroup
+    const uint32_t n_items = 9u * a.nb;
     const uint32_t units_tile = (a.TS / 13u) * 3u;                                  // pixels per tile
+    uint32_t cur = blockIdx.x, nxt = __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + kFx2Next + 4u));   // this interval's tile, the next one's
 
-    if (wave < 4u) {
+    if (wave < NW) {
         // ---------------- producers: S + E1, two passes of two sets per tile and wave ----------------
         const uint32_t n = lane & 31u, h = lane >> 5;
-        // one packed register of tile-independent geometry per (pass, set); made opaque inside the loop, or the compiler unpacks all
-        // four ahead of it and spills the pieces (80-VGPR budget)
-        Geo geo[2][2];
+        // one constant word and one byte offset (of the block in tile 0) per (pass, set) (t3_decode_fx2.h); the constant is made opaque
+        // inside the loop, or the compiler unpacks all four ahead of it and spills the pieces (80-VGPR budget)
+        Geo geo[2][2]; uint32_t off0[2][2];
+        const uint32_t t_off = 26u * a.nb;                                          // from a tile to the next one, in every band
 #pragma unroll
-        for (uint32_t p = 0; p < 2; ++p) for (uint32_t q = 0; q < 2; ++q) geo[p][q] = fx2_geo(wave * 128u + p * 64u + q * 32u + n, n_items, a.nb, a.div_nb);
-        auto blk = [&](uint32_t pass, uint32_t set, uint32_t tile, uint32_t y_off) -> Blk {
-            const uint32_t tb = tile * a.nb;
-            Geo g = geo[pass][set]; asm volatile("" : "+v"(g));
-            return fx2_block<R>(g, tb, mod3u(tb), y_off);
-        };
+        for (uint32_t p = 0; p < 2; ++p) for (uint32_t q = 0; q < 2; ++q) geo[p][q] = fx2_geo<R>(wave * 128u + p * 64u + q * 32u + n, n_items, a.nb, a.div_nb, 0u, off0[p][q]);
+        auto has = [&](uint32_t pass, uint32_t set, uint32_t tile) -> bool { Geo g = geo[pass][set]; asm volatile("" : "+v"(g)); return fx2_has_block<R>(g, tile, a.n_tiles, a.nb); };
         // lanes without a block read the first bytes of the body (always there) and ignore them
-        auto run_of = [&](const Blk& b) -> Run<BCN> { return load_run<BCN>(a, body, b.valid ? b.off + 10u * h : 0u); };
+        auto run_of = [&](uint32_t pass, uint32_t set, uint32_t tile) -> Run<BCN> { return load_run<BCN>(a, body, has(pass, set, tile) ? off0[pass][set] + tile * t_off + 10u * h : 0u); };
         Run<BCN> PA, PB;                                                           // the next pass's two sets, in flight
         PA.w = v4u32{0, 0, 0, 0}; PB.w = PA.w; if constexpr (BCN) { PA.x = 16u << 8; PB.x = PA.x; PA.w4 = 0; PB.w4 = 0; }
-        if (n_my) { PA = run_of(blk(0, 0, blockIdx.x, 0)); PB = run_of(blk(0, 1, blockIdx.x, 0)); }
-        for (uint32_t k = 0; k < n_my; ++k) {
-            const uint32_t tile = blockIdx.x + k * grid, buf = k & 1u;
+        if (cur < a.n_tiles) { PA = run_of(0, 0, cur); PB = run_of(0, 1, cur); }
+        for (uint32_t k = 0; cur < a.n_tiles; ++k) {
+            const uint32_t tile = cur, buf = k & 1u;
             const uint32_t y_off = a.y_off + buf * a.y_stride, q_off = a.q_off + buf * a.q_stride;
+            const uint32_t u2 = 2u * mod3u(tile * a.nb), toff = tile * t_off;
+            uint32_t raw; asm volatile("" : "=v"(raw));                                 // the counter value of lane 0's draw (no merge with a default: a copy would wait for it)
 #pragma unroll
             for (uint32_t pass = 0; pass < 2; ++pass) {
                 uint32_t LA[4], LB[4];
                 run_bytes<BCN>(PA, LA); run_bytes<BCN>(PB, LB);
-                {   // the next pass's input: in flight under this pass (the producers issue no stores, so it is waited for alone)
-                    const uint32_t np = pass ^ 1u, nt = pass == 0 ? tile : tile + grid;
-                    if (nt < a.n_tiles) { PA = run_of(blk(np, 0, nt, 0)); PB = run_of(blk(np, 1, nt, 0)); }
+                // the ticket for the tile after the next one: requested before this pass's loads, read after its work (the file is built
+                // without the compiler's atomic optimiser, which would read the counter back at once)
+                if (pass == 1u) {
+                    // (the previous pass's loads are taken into registers first: vmcnt completes in order, and behind the conditional draw
+                    // the compiler's conservative wait for them would cover the draw as well)
+                    asm volatile("" : "+v"(LA[0]), "+v"(LA[1]), "+v"(LA[2]), "+v"(LA[3]), "+v"(LB[0]), "+v"(LB[1]), "+v"(LB[2]), "+v"(LB[3]));
+                    if (tid == 0u && dyn) raw = atomicAdd(ctr, 1u);
                 }
-                if (wave * 128u + pass * 64u >= n_items) continue;                   // (wave-uniform) nothing left of the tile for this pass
-                const Blk bA = blk(pass, 0, tile, y_off), bB = blk(pass, 1, tile, y_off);
-                const Synd sA = fx2_set<R, TCOP, TBASE, MT>(bA, LA, lane, a.af_off, a.cyc24, a.pre0, a.pre1);
-                Synd sB; sB.lo = 0; sB.hi = 0;
-                if (wave * 128u + pass * 64u + 32u < n_items) sB = fx2_set<R, TCOP, TBASE, MT>(bB, LB, lane, a.af_off, a.cyc24, a.pre0, a.pre1);
-                fx2_own_blocks<R>(a.roots, a.fma_off, a.fail, sA, sB, bA, bB, (h ? geo[pass][1] : geo[pass][0]) & 0xFFFFu, lane, kFx2Cnt + 4u * buf, q_off, QCAP);
+                {   // the next pass's input: in flight under this pass (the producers issue no stores, so it is waited for alone)
+                    const uint32_t np = pass ^ 1u, nt = pass == 0 ? tile : nxt;
+                    if (nt < a.n_tiles) { PA = run_of(np, 0, nt); PB = run_of(np, 1, nt); }
+                }
+                if (wave * 128u + pass * 64u < n_items) {                             // (wave-uniform) else: nothing left of the tile for this pass
+                    Geo gA = geo[pass][0], gB = geo[pass][1]; asm volatile("" : "+v"(gA), "+v"(gB));
+                    const Blk bA = fx2_block(gA, off0[pass][0] + toff, fx2_has_block<R>(gA, tile, a.n_tiles, a.nb), u2, y_off);
+                    const Blk bB = fx2_block(gB, off0[pass][1] + toff, fx2_has_block<R>(gB, tile, a.n_tiles, a.nb), u2, y_off);
+                    const Synd sA = fx2_set<R, TCOP, TBASE, MT>(bA, LA, lane, a.af_off, a.pat_off);
+                    Synd sB; sB.lo = 0; sB.hi = 0;
+                    if (wave * 128u + pass * 64u + 32u < n_items) sB = fx2_set<R, TCOP, TBASE, MT>(bB, LB, lane, a.af_off, a.pat_off);
+                    fx2_own_blocks<R>(a.roots, a.fma_off, a.fail, sA, sB, bA, bB, (h ? gB : gA) & 0xFFFFu, lane, kFx2Cnt + 4u * buf, q_off, QCAP);
+                }
             }
+            if (tid == 0u) *(uint32_t*)(lds + kFx2Next + 4u * buf) = dyn ? cls + NC * (wgc + raw) : nxt + grid;
             T3D_STAMP(0);
             barrier_lds2();
             T3D_STAMP(1);
+            cur = nxt; nxt = __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + kFx2Next + 4u * buf));
         }
         barrier_lds2();                                                             // the consumers' last interval
     } else {
         // ---------------- consumers: BM + D5 of the tile the producers finished in the previous interval ----------------
-        const uint32_t cw = wave - 4u;
+        const uint32_t cw = wave - NW;
 #ifdef T3_DEC_CONS_PRIO
         __builtin_amdgcn_s_setprio(T3_DEC_CONS_PRIO);                               // the correction is one long dependent chain: let its steps issue first
 #endif
-        for (uint32_t k = 0; k <= n_my; ++k) {
+        uint32_t prev = 0;
+        for (uint32_t k = 0;; ++k) {
             if (k >= 1u) {
-                const uint32_t tile = blockIdx.x + (k - 1u) * grid, buf = (k - 1u) & 1u;
+                const uint32_t tile = prev, buf = (k - 1u) & 1u;
                 const uint32_t y_off = a.y_off + buf * a.y_stride, q_off = a.q_off + buf * a.q_stride;
                 const uint32_t Q = min(*(const uint32_t*)(lds + kFx2Cnt + 4u * buf), QCAP);
-                for (uint32_t e0 = cw * 64u; e0 < Q; e0 += 256u) { const uint32_t e = e0 + lane; if (e < Q) fx2_queue_entry<R>(a.roots, a.fma_off, a.fail, e, q_off, QCAP, y_off); }
+                for (uint32_t e0 = cw * 64u; e0 < Q; e0 += 64u * NW) { const uint32_t e = e0 + lane; if (e < Q) fx2_queue_entry<R>(a.roots, a.fma_off, a.fail, e, q_off, QCAP, y_off); }
                 T3D_STAMP(2);
-                // rendezvous of the four consumer waves: every patch is in LDS before any wave converts symbols
+                // rendezvous of the consumer waves: every patch is in LDS before any wave converts symbols
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 uint32_t* const sync = (uint32_t*)__builtin_assume_aligned(lds + kFx2Sync, 4);
                 if (lane == 0) __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 {
                     uint32_t spins = 0;
-                    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * k) {
+                    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NW * k) {
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > (1u << 22)) { if (lane == 0) { *(uint32_t*)(lds + kFx2Abort) = 1u; atomicAdd(a.fail, 1u << 20); } break; }   // never seen; a bound, not a path
                     }
                 }
-                if (tid == 256u) *(uint32_t*)(lds + kFx2Cnt + 4u * buf) = 0;         // every consumer has read Q; the producers touch this counter after the barrier
+                if (tid == 64u * NW) *(uint32_t*)(lds + kFx2Cnt + 4u * buf) = 0;         // every consumer has read Q; the producers touch this counter after the barrier
                 T3D_STAMP(3);
                 const uint64_t unit0 = (uint64_t)tile * units_tile;
                 const uint32_t n_here = (uint32_t)min((uint64_t)units_tile, a.n_units > unit0 ? a.n_units - unit0 : 0ull);
-                for (uint32_t j = cw * 64u + lane; 4u * j < a.TS / 13u; j += 256u) fx2_pixels12<RGB>(a, j, y_off, unit0, n_here);
+                for (uint32_t j = cw * 64u + lane; 4u * j < a.TS / 13u; j += 64u * NW) fx2_pixels12<RGB>(a, j, y_off, unit0, n_here);
                 T3D_STAMP(4);
             }
             barrier_lds2();
             T3D_STAMP(5);
+            if (cur >= a.n_tiles) break;                                            // the producers had no tile in this interval: that was their closing barrier
+            prev = cur; cur = nxt; nxt = __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + kFx2Next + 4u * (k & 1u)));
+        }
+    }
+    if (dyn && tid == 0u) {                                                          // re-arm the counters for the next launch on this stream: whoever finishes last
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(a.tile_ctr + 64u * NC, 1u) == grid - 1u) {
+            for (uint32_t c = 0; c <= NC; ++c) __hip_atomic_store(a.tile_ctr + 64u * c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 #ifdef T3_DEC_STAMPS
-    if ((tid == 0 || tid == 256) && a.dbg) {
+    if ((tid == 0 || tid == 64u * NW) && a.dbg) {
         uint64_t* d = a.dbg + 16ull * blockIdx.x + (tid ? 8 : 0);
         for (int i = 0; i < 6; ++i) d[i] = st_acc[i];
         d[6] = __builtin_amdgcn_s_memtime() - st_t0; d[7] = __builtin_amdgcn_s_memrealtime() - st_rt0;
@@ -271,32 +309,29 @@ __global__ __launch_bounds__(512, T3_DEC_WAVES_PER_EU) void decode_fixed_kernel(
     const uint32_t n_items = 9u * a.nb;
     const uint32_t units_tile = (a.TS / 26u) * 3u;                                  // words per tile
     const uint32_t n = lane & 31u, h = lane >> 5;
-    const Geo gA0 = fx2_geo(wave * 64u + n, n_items, a.nb, a.div_nb), gB0 = fx2_geo(wave * 64u + 32u + n, n_items, a.nb, a.div_nb);
+    uint32_t offA, offB;                                                           // running byte offsets of this wave's two blocks (t3_decode_fx2.h)
+    const Geo gA0 = fx2_geo<R>(wave * 64u + n, n_items, a.nb, a.div_nb, blockIdx.x, offA), gB0 = fx2_geo<R>(wave * 64u + 32u + n, n_items, a.nb, a.div_nb, blockIdx.x, offB);
+    const uint32_t d_off = 26u * a.nb * gridDim.x;
     Geo gA = gA0, gB = gB0;
-    auto run_of = [&](const Blk& b) -> Run<BCN> { return load_run<BCN>(a, body, b.valid ? b.off + 10u * h : 0u); };
+    auto run_of = [&](const Geo g, const uint32_t off, const uint32_t tile) -> Run<BCN> { return load_run<BCN>(a, body, fx2_has_block<R>(g, tile, a.n_tiles, a.nb) ? off + 10u * h : 0u); };
     Run<BCN> PA, PB;                                                               // this wave's two sets of the current tile, prefetched
     PA.w = v4u32{0, 0, 0, 0}; PB.w = PA.w; if constexpr (BCN) { PA.x = 16u << 8; PB.x = PA.x; PA.w4 = 0; PB.w4 = 0; }
-    if (blockIdx.x < a.n_tiles) {
-        PA = run_of(fx2_block<R>(gA, blockIdx.x * a.nb, mod3u(blockIdx.x * a.nb), a.y_off));
-        PB = run_of(fx2_block<R>(gB, blockIdx.x * a.nb, mod3u(blockIdx.x * a.nb), a.y_off));
-    }
+    if (blockIdx.x < a.n_tiles) { PA = run_of(gA, offA, blockIdx.x); PB = run_of(gB, offB, blockIdx.x); }
     uint32_t par = 0;
     for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x, par ^= 1u) {
-        const uint32_t tb = tile * a.nb, t3 = mod3u(tb);
+        const uint32_t u2 = 2u * mod3u(tile * a.nb);
         asm volatile("" : "+v"(gA), "+v"(gB));                                     // opaque: keeps the unpacked pieces out of loop-long registers
-        const Blk bA = fx2_block<R>(gA, tb, t3, a.y_off), bB = fx2_block<R>(gB, tb, t3, a.y_off);
+        const Blk bA = fx2_block(gA, offA, fx2_has_block<R>(gA, tile, a.n_tiles, a.nb), u2, a.y_off), bB = fx2_block(gB, offB, fx2_has_block<R>(gB, tile, a.n_tiles, a.nb), u2, a.y_off);
         uint32_t LA[4], LB[4];
         run_bytes<BCN>(PA, LA); run_bytes<BCN>(PB, LB);
-        const Synd sA = fx2_set<R, TCOP, TBASE, MT>(bA, LA, lane, a.af_off, a.cyc24, a.pre0, a.pre1);
-        const Synd sB = fx2_set<R, TCOP, TBASE, MT>(bB, LB, lane, a.af_off, a.cyc24, a.pre0, a.pre1);
+        const Synd sA = fx2_set<R, TCOP, TBASE, MT>(bA, LA, lane, a.af_off, a.pat_off);
+        const Synd sB = fx2_set<R, TCOP, TBASE, MT>(bB, LB, lane, a.af_off, a.pat_off);
         {   // the next tile's input, in flight under this tile's correction phase
             const uint32_t nt = tile + gridDim.x;
-            if (nt < a.n_tiles) {
-                PA = run_of(fx2_block<R>(gA, nt * a.nb, mod3u(nt * a.nb), a.y_off));
-                PB = run_of(fx2_block<R>(gB, nt * a.nb, mod3u(nt * a.nb), a.y_off));
-            }
+            offA += d_off; offB += d_off;
+            if (nt < a.n_tiles) { PA = run_of(gA, offA, nt); PB = run_of(gB, offB, nt); }
         }
-        fx2_own_blocks<R>(a.roots, a.fma_off, a.fail, sA, sB, bA, bB, (h ? gB0 : gA0) & 0xFFFFu, lane, kFx2Cnt + 4u * par, a.q_off, 512u);
+        fx2_own_blocks<R>(a.roots, a.fma_off, a.fail, sA, sB, bA, bB, (h ? gB0 : gA0) & 0xFFFFu, lane, kFx2Cnt + 4u * par, a.q_off, 512u);   // (bA / bB were built before the offsets advanced)
         barrier_lds2();
         {
             const uint32_t Q = *(const uint32_t*)(lds + kFx2Cnt + 4u * par);

@@ -12,6 +12,10 @@
 #include "t3_decode_fx.h"
 #include "t3_host.hpp"
 
+#ifndef T3_DEC_FOLD_VALU
+#define T3_DEC_FOLD_VALU 0   // 1: mod-3 fold on the vector ALU instead of three byte-table reads per syndrome -- measured slower (0.153 -> 0.158 ms): the kernel is bound by vector issue
+#endif
+
 namespace t3 {
 namespace {
 
@@ -25,32 +29,48 @@ __device__ __forceinline__ uint32_t mod26(uint32_t u) { return min(u, u + 26u); 
 // What a set leaves with the two lanes of a block: the r syndromes, h = 0 half (S_0 .. S_{r/2-1}, one byte each) and h = 1 half
 struct Synd { uint32_t lo, hi; };
 
-// geometry of one block seen by its two lanes.  Geo is the tile-independent part (item -> band index, block within the tile).
-// One register per (lane, set): m | bi << 12 | m mod 3 << 16 | has-an-item << 18.
+// Geometry of one block seen by its two lanes, per set a lane works on: a constant word and a running byte offset.
+//   Geo (constant): y_rel = band + 9 K m, where the block's symbols start in a tile's symbol buffer (m = block within the tile: also
+//                   the queue tag) | cbase << 16, the scrambler phase (boff6 + 2 (m mod 3)) mod 6 of the block in tile 0 | has-an-item << 19
+//   off (running):  byte offset of the block from the body's first symbol; a workgroup's next tile is nb * grid blocks further on in
+//                   every band, so it advances by one wave-uniform constant per tile.
+// Round 2 rebuilt all of this from (item, tile) for every set and every prefetch -- a table row read and ~20 vector instructions, four
+// times per pass: an eighth of the kernel's vector instructions.
 typedef uint32_t Geo;
 struct Blk { bool valid, first; uint32_t c0, off, yb; };            // off: byte offset of the block from the body's first symbol
 constexpr uint32_t kFx2Dummy = 384;                                   // 128 bytes of LDS that take the writes of lanes without a block
 
-__device__ __forceinline__ Geo fx2_geo(const uint32_t item, const uint32_t n_items, const uint32_t nb, const DevDiv& div_nb) {
+template <int R>
+__device__ __forceinline__ Geo fx2_geo(const uint32_t item, const uint32_t n_items, const uint32_t nb, const DevDiv& div_nb, const uint32_t tile0, uint32_t& off0) {
+    constexpr uint32_t K = 26 - R;
     const uint32_t bi = min(__umulhi(item, div_nb.mul) >> div_nb.sh, 8u), m = item - bi * nb;       // nb >= 2
     const uint32_t m3 = m - 3u * ((m * 683u) >> 11);                                                // m < 2048
-    return m | bi << 12 | m3 << 16 | (item < n_items ? 1u << 18 : 0u);
-}
-// tb = tile * nb and t3 = tb mod 3 are wave-uniform
-template <int R>
-__device__ __forceinline__ Blk fx2_block(const Geo g, const uint32_t tb, const uint32_t t3, const uint32_t y_off) {
-    constexpr uint32_t K = 26 - R;
-    const uint32_t gm = g & 0xFFFu, bi = (g >> 12) & 15u, gm3 = (g >> 16) & 3u;
     const Row rw = row(bi);
-    const uint32_t mg = tb + gm, boff = (uint32_t)rw.body_off;            // the coded stream is shorter than 4 GiB (t3_api_decode.cpp)
+    uint32_t cb = rw.boff6 + 2u * m3; cb -= cb >= 6u ? 6u : 0u;                                     // 26 == 2 (mod 6)
+    off0 = (uint32_t)rw.body_off + 26u * (tile0 * nb + m);                                          // the coded stream is shorter than 4 GiB (t3_api_decode.cpp)
+    return (bi + 9u * K * m) | cb << 16 | (item < n_items ? 1u << 19 : 0u);
+}
+// A band's blocks end inside its last tile only (the bands of a uniform-k frame differ by at most one block): every other tile holds a
+// block for every item, so the per-lane test against the band's block count -- a table row read -- runs for the last tile alone.
+template <int R>
+__device__ __forceinline__ bool fx2_has_block(const Geo g, const uint32_t tile, const uint32_t n_tiles, const uint32_t nb) {
+    constexpr uint32_t K = 26 - R;
+    bool v = (g >> 19) != 0u;
+    if (tile + 1u >= n_tiles) {                                                                     // (wave-uniform)
+        const uint32_t yr = g & 0xFFFFu, m = yr / (9u * K), bi = yr - 9u * K * m;
+        v = v && tile * nb + m < row(bi).blocks;
+    }
+    return v;
+}
+// u2 = 2 ((tile nb) mod 3), wave-uniform
+__device__ __forceinline__ Blk fx2_block(const Geo g, const uint32_t off, const bool valid, const uint32_t u2, const uint32_t y_off) {
     Blk b;
-    b.valid = (g >> 18) != 0u && mg < rw.blocks;
-    b.first = boff == 0u && mg == 0u;
-    uint32_t s3 = gm3 + t3; s3 -= s3 >= 3u ? 3u : 0u;                    // mg mod 3
-    uint32_t c0 = rw.boff6 + 2u * s3; c0 -= c0 >= 6u ? 6u : 0u;          // 26 == 2 (mod 6)
+    b.valid = valid;
+    b.first = off == 0u;                                                  // block 0 of band 0
+    uint32_t c0 = ((g >> 16) & 7u) + u2; c0 -= c0 >= 6u ? 6u : 0u;
     b.c0 = c0;
-    b.off = boff + 26u * mg;
-    b.yb = y_off + bi + 9u * K * gm;
+    b.off = off;
+    b.yb = y_off + (g & 0xFFFFu);
     return b;
 }
 
@@ -59,9 +79,8 @@ __device__ __forceinline__ Blk fx2_block(const Geo g, const uint32_t tb, const u
 // TCOP bank copies of the T table at LDS offset TBASE (32: conflict-free; 16: lanes n and n + 16 share a copy, two-way conflicts,
 // half the space); MT: LDS offset of the fold tables (a compile-time constant, so that it rides in the instruction's offset field).
 template <int R, uint32_t TCOP, uint32_t TBASE, uint32_t MT, uint32_t SMB = 0>
-__device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], const uint32_t lane, const uint32_t af_off,
-                                        const uint32_t cyc24, const uint32_t pre0, const uint32_t pre1) {
-    constexpr uint32_t TSTATE = 27u * 4u * TCOP, mt = MT;
+__device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], const uint32_t lane, const uint32_t af_off, const uint32_t pat_off) {
+    constexpr uint32_t mt = MT;
     constexpr uint32_t K = 26 - R, H = R / 2;
     const uint32_t n = lane & 31u, h = lane >> 5;
     // symbol q of this lane (position 13 h + q) = byte q of W: h = 1 starts at byte 3 of its load
@@ -82,16 +101,16 @@ __device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], c
             W[i] = r;
         }
     }
-    // scrambler state of position 13 h + q: cyc[(c0 + 13 h + q) mod 6], 13 == 1 (mod 6)
+    // Scrambler state of position 13 h + q: cyc[(c0 + 13 h + q) mod 6], 13 == 1 (mod 6).  The T table is state-major (entry 27 s + c), so
+    // the state rides in the symbol byte itself: one 16-byte row of 27 s per position class start (host-built, t3_api_decode.cpp; row 6:
+    // the stream's first block, whose symbols 0 and 1 see the pre-period states) is added to the 13 bytes -- c + 27 s <= 80, no carries --
+    // instead of a table base per position class (round 2: twelve multiply-adds and four selects per set).
     uint32_t c0h = b.c0 + h; c0h -= c0h >= 6u ? 6u : 0u;
-    const uint32_t cycs = cyc24 >> (2u * c0h);
-    const uint32_t tb0 = TBASE + 4u * (n % TCOP);
-    uint32_t vb[6];                                                               // T base per position class: state, own bank copy
+    const uint32_t prow = (b.first && h == 0u) ? 6u : c0h;
+    const v4i_ P = *T3_LP(const v4i_, pat_off + 16u * prow);
 #pragma unroll
-    for (uint32_t q = 0; q < 6; ++q) vb[q] = __umul24((cycs >> (2u * q)) & 3u, TSTATE) + tb0;
-    const bool fst = b.first && h == 0;                                            // body symbols 0 and 1 see the pre-period states
-    const uint32_t vb0 = fst ? pre0 * TSTATE + tb0 : vb[0];
-    const uint32_t vb1 = fst ? pre1 * TSTATE + tb0 : vb[1];
+    for (int i = 0; i < 4; ++i) W[i] += (uint32_t)P[i];
+    const uint32_t tb0 = 4u * (n % TCOP);                                          // own bank copy; entries are 4 TCOP bytes apart: disjoint bits
     // data symbols -> stream order (byte 2 of a T entry = the descrambled symbol): h = 0 holds positions 0..12, h = 1 13..25, of
     // which K..25 are parity; lanes without a block write into a dummy area instead of being masked off store by store
     const uint32_t ya = b.valid ? b.yb + 117u * h : SMB + kFx2Dummy;               // 9 * 13
@@ -106,9 +125,8 @@ __device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], c
         for (uint32_t d = 0; d < 4; ++d) {
             const uint32_t q = 4u * st + d;
             if (q >= 13u) continue;
-            const uint32_t c = (W[st] >> (8u * d)) & 0xFFu;
-            const uint32_t base = q == 0 ? vb0 : q == 1 ? vb1 : vb[q % 6u];
-            Bv[d] = (int)*T3_LP(const uint32_t, c * (4u * TCOP) + base);
+            const uint32_t c = __builtin_amdgcn_ubfe(W[st], 8u * d, 8u);              // 27 state + symbol
+            Bv[d] = (int)*T3_LP(const uint32_t, TBASE + ((c * (4u * TCOP)) | tb0));
         }
     };
     auto emit = [&](const uint32_t st, const v4i_& Bv) {       // data symbols of the step -> stream order
@@ -135,8 +153,23 @@ __device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], c
     }
     uint32_t Pown = 0;
 #pragma unroll
-    for (uint32_t jj = 0; jj < H; ++jj) {                                          // mod-3 fold and 3^t weight by byte tables
+    for (uint32_t jj = 0; jj < H; ++jj) {
+#if T3_DEC_FOLD_VALU
+        // mod-3 fold on the vector ALU (the LDS pipe is the busier one: three byte-table reads per syndrome become twelve integer
+        // operations): a biased trit sum x in [-14, 142] has x + 14 = (trit sum) + 78 == trit sum (mod 3) and x + 14 < 512, so
+        // q = ((x + 14) * 171) >> 9 = floor((x + 14) / 3); the three residues x_t + 14 - 3 q_t are weighted 1 / 3 / 9
+        uint32_t u[3];
+#pragma unroll
+        for (uint32_t t = 0; t < 3; ++t) {
+            const uint32_t x = (uint32_t)acc[3 * jj + t];
+            const uint32_t q = __umul24(x + 14u, 171u) >> 9;                          // (one v_mad_u32_u24 + shift)
+            u[t] = x - 3u * q;                                                        // residue - 14
+        }
+        const uint32_t s = u[0] + 3u * u[1] + 9u * u[2] + 14u * 13u;
+#else
+        // mod-3 fold and 3^t weight by byte tables
         const uint32_t s = l8(mt + 14u + (uint32_t)acc[3 * jj]) + l8(mt + 174u + (uint32_t)acc[3 * jj + 1]) + l8(mt + 334u + (uint32_t)acc[3 * jj + 2]);
+#endif
         Pown |= s << (8u * jj);
     }
     const auto sw = __builtin_amdgcn_permlane32_swap(Pown, Pown, false, false);    // [0]: every lane sees the h = 0 half, [1]: the h = 1 half
@@ -351,19 +384,18 @@ __device__ __forceinline__ void fx2_own_blocks(const uint32_t* __restrict__ root
             const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
             if (__builtin_expect(slot < qcap, 1)) {
                 *T3_LP(u32x2, q_off + 8u * slot) = u32x2{own.lo, own.hi};              // the r syndromes ...
-                *T3_LP(uint16_t, q_off + 8u * qcap + 2u * slot) = (uint16_t)tag;       // ... and the block: block within the tile | band << 12
+                *T3_LP(uint16_t, q_off + 8u * qcap + 2u * slot) = (uint16_t)tag;       // ... and the block: where its symbols start in the tile's buffer
             } else if (!fx2_fix_block<R, SMB>(own.lo, own.hi, yb, roots, fma_off)) atomicAdd(fail, 1u);   // queue full (cold)
         }
     }
 }
 
-// BM for queue entry e: the block's symbols are at y_off + band + 9 K (block within the tile)
+// BM for queue entry e: the block's symbols are at y_off + tag, tag = band + 9 K (block within the tile)
 template <int R, uint32_t SMB = 0>
 __device__ __forceinline__ void fx2_queue_entry(const uint32_t* __restrict__ roots, const uint32_t fma_off, uint32_t* fail, const uint32_t e, const uint32_t q_off, const uint32_t qcap, const uint32_t y_off) {
-    constexpr uint32_t K = 26 - R;
     const u32x2 sy = *T3_LP(const u32x2, q_off + 8u * e);
     const uint32_t tag = *T3_LP(const uint16_t, q_off + 8u * qcap + 2u * e);
-    if (!fx2_fix_block<R, SMB>(sy.x, sy.y, y_off + (tag >> 12) + 9u * K * (tag & 0xFFFu), roots, fma_off)) atomicAdd(fail, 1u);
+    if (!fx2_fix_block<R, SMB>(sy.x, sy.y, y_off + tag, roots, fma_off)) atomicAdd(fail, 1u);
 }
 
 }  // namespace
