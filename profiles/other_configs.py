@@ -31,6 +31,11 @@ def run(name, cfg, words=False):
     return {"config": name, "ms": round(ms, 4), "coded_words": n_enc, "GBps": round((6 * NPX if not words else 9 * n_raw) / ms / 1e6 + 9 * n_enc / ms / 1e6, 1)}
 res = []
 P = t3.ProfileID
+_only = [a.lower() for a in sys.argv[1:]]                      # optional substrings: run only the configurations whose name holds one of them
+_run = run
+def run(name, cfg, words=False):
+    if _only and not any(o in name.lower() for o in _only): return None
+    return _run(name, cfg, words)
 res.append(run("C2 pixels, RS(26,20) all bands, 1-D, COMPAT", t3.make_cfg(profile=P.P3_RS26_20, uep=2)))
 res.append(run("C2 same, FIXED", t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=t3.MODE_FIXED)))
 res.append(run("C2 raw words in (encode_profile), COMPAT", t3.make_cfg(profile=P.P3_RS26_20, uep=2), words=True))
@@ -44,4 +49,5 @@ res.append(run("1-D four different k per frame (bands 24,22,20,18,...)", t3.make
 res.append(run("2-D wide rows 1024x16, RS(26,20) all bands", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(1024, 16))))
 res.append(run("2-D wide rows 7680x8, RS(26,20) all bands", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(7680, 8))))
 res.append(run("2-D odd tile 7x5, RS(26,20) all bands", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(7, 5))))
+res = [r for r in res if r is not None]
 print(json.dumps(res, indent=1))

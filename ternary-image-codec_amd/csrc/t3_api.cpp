@@ -173,6 +173,17 @@ uint32_t p1_waves_per_parity(uint32_t TS) {
     return (worst + 63) / 64;
 }
 
+// ... and for raw words (1-D): four word triples = 104 symbols per lane (convert_words_packed)
+uint32_t p1_waves_words(uint32_t TS) {
+    uint32_t worst = 0;
+    for (uint32_t t = 0; t < 104; ++t) {
+        const uint64_t S0 = (uint64_t)t * TS;
+        const uint64_t t_base = (S0 / 26) & ~3ull, t_end = (S0 + TS + 25) / 26;
+        worst = std::max<uint32_t>(worst, (uint32_t)((t_end - t_base + 3) / 4));
+    }
+    return (worst + 63) / 64;
+}
+
 // grp = true: UEP on the matrix cores (all nine bands, several k): bands are grouped by k, a group's blocks of a tile are
 // dealt linearly into sets of 32; eight waves take two sets each
 bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, int fe, const LutImage& lut, EncLaunch& out, bool grp = false) {
@@ -191,6 +202,8 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     const uint32_t il_extra = il_async == 1u ? 2u * cfg.tile_w : 0u;
     const uint32_t il_stage = il_async == 2u ? 2u * (1024u + 4u * GB + 32u) : 0u;   // two more runs: their rounding and pitch
     const uint32_t hdr = grp ? (uint32_t)kLdsHdrUep : (uint32_t)kLdsHdr;
+    const bool words_packed = fe == FE_WORDS && !il2d;                     // 1-D raw words: the packed converter (whole lanes of 104 symbols: wider slack)
+    const uint32_t sym_front = words_packed ? (uint32_t)kSymSlackW : (uint32_t)kSymFront, sym_back = words_packed ? (uint32_t)kSymSlackW : (uint32_t)kSymBack;
     bool mixed = false;
     { int k0 = 0; for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) { if (!k0) k0 = L.band_k[b]; else if (k0 != L.band_k[b]) mixed = true; } }
     // pick q: tile = 9*Lk*q stream symbols; band b then owns Lk*q/k_b blocks
@@ -219,15 +232,15 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
             const uint32_t groups = (uint32_t)((9 * Lq + il_extra) / GS) + 8;
             uint32_t stage = groups * GB + 1024 + 32 + il_stage;                                              // +1 KiB: LDS-DMA pieces are whole
             if (il_async == 1u) stage = std::max<uint32_t>(stage, (uint32_t)(9 * Lq) + 64u);                  // the permutation pass writes the tile's 9 Lq symbols into the consumed stage buffer (RGB input is smaller than that)
-            const uint32_t total = hdr + round16(lut_bytes) + kSymFront + round16((uint32_t)(9 * Lq) + il_extra) + kSymBack + ((il2d && !il_async) ? 1u : 2u) * round16(stage) + (fe == FE_RGB ? 256u : 0u);
+            const uint32_t total = hdr + round16(lut_bytes) + sym_front + round16((uint32_t)(9 * Lq) + il_extra) + sym_back + ((il2d && !il_async) ? 1u : 2u) * round16(stage) + (fe == FE_RGB ? 256u : 0u);
             if (total > budget) break;
             // wave-instructions per stream symbol: phase 2 costs ~180 per wave, phase 1 (pixels) ~120 per wave-iteration
-            const uint32_t wpp = p1_waves_per_parity((uint32_t)(9 * Lq) + il_extra + (il_async == 2u ? 312u : 0u));   // (three runs: up to six lane units of rounding)
-            if (fe_px(fe) && wpp > std::max(waves, 4u)) continue;
+            const uint32_t wpp = words_packed ? p1_waves_words((uint32_t)(9 * Lq)) : p1_waves_per_parity((uint32_t)(9 * Lq) + il_extra + (il_async == 2u ? 312u : 0u));   // (three runs: up to six lane units of rounding)
+            if ((fe_px(fe) || words_packed) && (words_packed ? 2u : 1u) * wpp > std::max(waves, 4u)) continue;
             // UEP kernel: the phases are barrier-separated and a wave runs its sets one after the other, so a tile costs one
             // phase-1 pass plus ceil(sets / 8) set times, whatever the number of busy waves
             const double cost = grp ? (220.0 + 100.0 * ((sets + 7) / 8)) / (double)(9 * Lq)
-                                    : (180.0 * waves + (fe_px(fe) ? 220.0 * wpp : 180.0 * waves)) / (double)(9 * Lq);
+                                    : (180.0 * waves + (fe_px(fe) ? 220.0 * wpp : words_packed ? 250.0 * wpp : 180.0 * waves)) / (double)(9 * Lq);
             const double score = 1.0 / cost + 1e-9 * (double)Lq;
             if (score > best_score) { best_score = score; best_q = q; }
         }
@@ -236,7 +249,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
     const uint32_t Lq = (uint32_t)(Lk * best_q);
     a.Lq = Lq; a.lut_bytes = round16(lut_bytes);
     uint32_t off = hdr + a.lut_bytes;
-    off += kSymFront; a.sym_off = off; off += round16(9 * Lq + il_extra) + kSymBack;   // slack either side: phase 1 writes whole pixel triples
+    off += sym_front; a.sym_off = off; off += round16(9 * Lq + il_extra) + sym_back;   // slack either side: phase 1 writes whole pixel triples / whole lanes of word triples
     a.stage_off = off;
     a.stage_groups = (9 * Lq + il_extra) / GS + 8;
     uint32_t nw = 0, n_tiles = 0;
@@ -267,7 +280,7 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
         a.div_A = to_dev(fastdiv(a.il_A)); a.div_w = to_dev(fastdiv(a.il_w));
     }
     out.block = 64u * std::max<uint32_t>((nw + 63) / 64, 4u);
-    a.p1_wpp = p1_waves_per_parity(9 * Lq + il_extra + (il_async == 2u ? 312u : 0u));
+    a.p1_wpp = words_packed ? p1_waves_words(9 * Lq) : p1_waves_per_parity(9 * Lq + il_extra + (il_async == 2u ? 312u : 0u));
     out.rsel = 0;
     { int k0 = 0; bool same = true; for (int b = 0; b < 9; ++b) if (band_mask >> b & 1) { if (!k0) k0 = L.band_k[b]; else if (k0 != L.band_k[b]) same = false; } if (same && k0 && band_mask == 0x1FF) out.rsel = 26 - k0; }
     a.nb_uniform = out.rsel ? a.band_nb_tile[0] : 0u; a.div_nb = to_dev(fastdiv(a.nb_uniform ? a.nb_uniform : 1u));

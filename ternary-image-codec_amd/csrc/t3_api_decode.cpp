@@ -139,9 +139,9 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
     a.n_tiles = (uint32_t)((maxb + a.nb - 1) / a.nb);
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
     {   // body symbol i >= 2 sees cyc[(i - 2) mod 6]; a block whose first symbol has phase c0 = (i0 + 4) mod 6 sees cyc[(c0 + p) mod 6] at position p
-        uint8_t rows[7][16]; memset(rows, 0, sizeof rows);
-        for (int r = 0; r < 6; ++r) for (int q = 0; q < 13; ++q) rows[r][q] = (uint8_t)(27u * sc.cyc[(r + q) % 6]);
-        for (int q = 0; q < 13; ++q) rows[6][q] = (uint8_t)(27u * (q == 0 ? sc.pre[0] : q == 1 ? sc.pre[1] : sc.cyc[(4 + q) % 6]));   // the stream's first block: c0 = 4
+        uint8_t rows[12][16]; memset(rows, 0, sizeof rows);
+        for (int r = 0; r < 11; ++r) for (int q = 0; q < 13; ++q) rows[r][q] = (uint8_t)(27u * sc.cyc[(r + q) % 6]);     // rows 0..10: the phase arrives un-reduced
+        for (int q = 0; q < 13; ++q) rows[11][q] = (uint8_t)(27u * (q == 0 ? sc.pre[0] : q == 1 ? sc.pre[1] : sc.cyc[(4 + q) % 6]));   // the stream's first block: c0 = 4
         memcpy(a.pat, rows, sizeof rows);
     }
     const bool bcn = bcn_period != 0;
@@ -152,7 +152,7 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
         a.fma_off = (uint32_t)kFx2TPx + 3u * 27u * 4u * (uint32_t)T3_DEC_PX_TCOP;
         a.af_off = a.fma_off + 19696u;
         a.pat_off = a.af_off + 3328u;
-        a.y_off = a.pat_off + 128u; a.y_stride = ybytes;
+        a.y_off = a.pat_off + 192u; a.y_stride = ybytes;
         a.q_off = a.y_off + 2u * ybytes; a.q_stride = 10u * (uint32_t)kFx2QCap;    // 8 bytes of syndromes + 2 of item number per entry
         a.o_off = a.q_off + 2u * a.q_stride; a.dq_off = a.o_off;
         a.lds_bytes = a.o_off + (rgb ? 336u : 16u);                                 // <= 42 x 1280 B: LDS is handed out in 1280-byte units, 128 per CU (three workgroups)
@@ -160,7 +160,7 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
         a.fma_off = (uint32_t)kFx2TSeq + 3u * 27u * 4u * 32u;
         a.af_off = a.fma_off + 19696u;
         a.pat_off = a.af_off + 3328u;
-        a.y_off = a.pat_off + 128u; a.y_stride = 0;
+        a.y_off = a.pat_off + 192u; a.y_stride = 0;
         a.q_off = a.y_off + ybytes; a.q_stride = 0;
         a.o_off = a.q_off + 10u * 512u;
         a.lds_bytes = a.o_off + (a.TS / 26u) * 27u + 64u;

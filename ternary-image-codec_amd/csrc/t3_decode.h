@@ -116,7 +116,7 @@ struct DecFx2Args {
     uint32_t band_blocks[9]; uint64_t band_body_off[9]; uint32_t band_boff6[9];
     uint32_t cyc24, pre0, pre1;
     uint32_t* tile_ctr; uint32_t n_classes;    // px kernel: dynamic tile tickets (n_classes counters + a done counter, 256 B apart; zero between launches); null = static stride
-    uint32_t pat[28], pat_off;                 // seven 16-byte rows: byte q of row r < 6 = 27 x scrambler state of a position of class (r + q) mod 6; row 6: the stream's first block (pre-period states in bytes 0, 1)
+    uint32_t pat[48], pat_off;                 // twelve 16-byte rows: byte q of row r < 11 = 27 x scrambler state of a position of class (r + q) mod 6; row 11: the stream's first block (pre-period states in bytes 0, 1)
     uint32_t y_off, y_stride, q_off, q_stride, o_off, af_off, lds_bytes;   // px kernel: two symbol buffers / queues, y_stride / q_stride apart
     uint32_t bcn_slot, bcn_pb; DevDiv bcn_div;   // BCN kernels: a beacon symbol sits in front of body byte bcn_slot + j bcn_pb (bcn_pb = 9 period - 1 >= 17); `in` is the framed stream
     const uint8_t* dq; uint32_t dq_off;          // RGB out (row f1 fused): dequantiser tables yd[244] | cd[84] (t3_rgb.h) and their LDS offset

@@ -94,7 +94,7 @@ __device__ __forceinline__ void stage_tables(const DecFx2Args& a, const uint32_t
     if (tid < 64u) *(uint32_t*)(lds + a.af_off + 3072u + 4u * tid) = a.afrag[(3u * 64u + tid) * 4u];       // step 3: dword 0 of every lane
     if (tid == 64u) {                                                                // scrambler pattern rows (t3_decode_fx2.h, fx2_set): constant indices only
 #pragma unroll
-        for (int i = 0; i < 28; ++i) *(uint32_t*)(lds + a.pat_off + 4 * i) = a.pat[i];
+        for (int i = 0; i < 48; ++i) *(uint32_t*)(lds + a.pat_off + 4 * i) = a.pat[i];
     }
 }
 

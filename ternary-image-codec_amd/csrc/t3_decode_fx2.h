@@ -67,8 +67,7 @@ __device__ __forceinline__ Blk fx2_block(const Geo g, const uint32_t off, const 
     Blk b;
     b.valid = valid;
     b.first = off == 0u;                                                  // block 0 of band 0
-    uint32_t c0 = ((g >> 16) & 7u) + u2; c0 -= c0 >= 6u ? 6u : 0u;
-    b.c0 = c0;
+    b.c0 = ((g >> 16) & 7u) + u2;                                        // scrambler phase of the block's first symbol, NOT reduced mod 6 (<= 9)
     b.off = off;
     b.yb = y_off + (g & 0xFFFFu);
     return b;
@@ -104,9 +103,9 @@ __device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], c
     // Scrambler state of position 13 h + q: cyc[(c0 + 13 h + q) mod 6], 13 == 1 (mod 6).  The T table is state-major (entry 27 s + c), so
     // the state rides in the symbol byte itself: one 16-byte row of 27 s per position class start (host-built, t3_api_decode.cpp; row 6:
     // the stream's first block, whose symbols 0 and 1 see the pre-period states) is added to the 13 bytes -- c + 27 s <= 80, no carries --
-    // instead of a table base per position class (round 2: twelve multiply-adds and four selects per set).
-    uint32_t c0h = b.c0 + h; c0h -= c0h >= 6u ? 6u : 0u;
-    const uint32_t prow = (b.first && h == 0u) ? 6u : c0h;
+    // instead of a table base per position class (round 2: twelve multiply-adds and four selects per set).  c0 comes un-reduced
+    // (cbase + 2 ((tile nb) mod 3) <= 9), the row table simply repeats.
+    const uint32_t prow = (b.first && h == 0u) ? 11u : b.c0 + h;                    // c0 + h <= 10 un-reduced: rows 6..10 repeat rows 0..4
     const v4i_ P = *T3_LP(const v4i_, pat_off + 16u * prow);
 #pragma unroll
     for (int i = 0; i < 4; ++i) W[i] += (uint32_t)P[i];

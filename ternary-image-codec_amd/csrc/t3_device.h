@@ -16,6 +16,7 @@ constexpr int kHdrGrp = 384, kHdrGrpStride = 96, kHdrSets = 768;   // header off
 constexpr int kMaxGrp = 4, kMaxSets = 16;
 constexpr int kSymFront = 64;           // slack in front of the LDS symbol buffer (phase 1 writes whole pixel triples) ...
 constexpr int kSymBack = 64;            // ... and behind it
+constexpr int kSymSlackW = 112;         // raw words (1-D, packed converter): a lane writes four word triples = 104 symbols whole, either side
 constexpr int kGroupSyms = 26;           // symbols one phase-1 lane produces from pixels: 6 px = 36 B -> 26 symbols
 constexpr int kGroupBytes = 36;
 constexpr int kGroupSymsW = 52;          // from raw words: 6 words = 54 B -> 52 symbols

@@ -892,6 +892,122 @@ __device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, const P1
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Phase 1 for raw words, packed (1-D; the reference's own entry encode_profile_from_raw OLD:1043, regroup OLD:1051-1082): 3 words = 27
+// symbol bytes of which trit 26 of every word is dropped = 78 trits = 26 symbols.  One lane = FOUR word triples = 108 input bytes =
+// 27 aligned dwords -> 104 symbols = 26 aligned dwords (round 2 gave a lane one group of 6 words through 28 16-bit LDS reads and a
+// division per symbol: 0.111 ms per 8K frame against 0.086 for pixels).  With c[0..26] the triple's bytes:
+//   s[m] = c[m]                                  m < 8            (word 0 as it is)
+//   s[m] = H(c[m]) + W Lo(c[m+1])                m = 8 .. 25      (word 1 shifted by one trit, word 2 by two)
+//     m = 8: c%9 + 9 (c'%3);  9..16: c/3 + 9 (c'%3);  17: (c/3)%3 + 3 (c'%9);  18..25: c/9 + 3 (c'%9)
+// computed on pairs (c[8+2i], c[9+2i]) in the 16-bit halves of a register (v_pk_*): H and Lo are element-wise, the pairing of
+// Lo(c[m+1]) with H(c[m]) is one v_alignbit per output pair.  Triples are written whole (slack either side of the symbol buffer:
+// kSymSlackW); the stage buffer holds real input for all four triples of every live lane (stage_tile rounds up), so stale bytes
+// never enter the range check.  Symbols are stored pre-scaled by 2^SH like the pixel converter's.
+// ---------------------------------------------------------------------------------------------------------
+struct W1Run { uint32_t t_base, t_end, n_units, src0; };      // word triples [t_base, t_end), lane units of four; triple t reads its 27 bytes at src0 + 27 t
+__device__ __forceinline__ W1Run w1_run(uint32_t u_lo, uint32_t u_hi, uint32_t stage) {
+    W1Run r; r.t_base = (u_lo / 26u) & ~3u; r.t_end = (u_hi + 25u) / 26u; r.n_units = (r.t_end - r.t_base + 3u) / 4u;
+    const uint64_t b0 = ((uint64_t)(r.t_base / 2u) * kGroupBytesW) & ~15ull;              // 16-aligned start of the first lane group (two triples each): stage_input
+    r.src0 = stage - (uint32_t)b0;                                                         // (wraps; src0 + 27 t does not)
+    return r;
+}
+// A lane unit's two halves (two triples each) go to two different waves -- even converting waves take half 0, odd ones half 1, so the
+// byte selectors stay compile-time constants -- which halves the length of phase 1, a serial section of the tile (a wave alone issues a
+// vector instruction every four to five cycles).
+template <int SH, uint32_t HALF>
+__device__ __forceinline__ void convert_words_half(const EncArgs& a, const W1Run r, uint32_t S0, uint32_t lane, uint32_t uw, uint32_t nuw) {
+    for (uint32_t e0 = uw * 64u; e0 < r.n_units; e0 += nuw * 64u) {
+        const uint32_t e = e0 + lane;
+        const uint32_t t = r.t_base + 4u * e;
+        const bool live = t < r.t_end;
+        const uint32_t src = r.src0 + 27u * (live ? t : r.t_base);                          // dword aligned
+        const uint32_t dst = a.sym_off + 26u * t - S0;                                       // dword aligned; may sit below sym_off (front slack)
+        {                                                                                    // two triples = 54 bytes in, 52 symbols = 13 dwords out
+            constexpr uint32_t half = HALF;
+            constexpr uint32_t kDw = 14;
+            const uint32_t w0b = 54u * half, d0 = w0b >> 2, B0 = w0b & 3u;                    // the half's bytes start B0 bytes into its first dword
+            uint32_t D[kDw];
+#pragma unroll
+            for (uint32_t i = 0; i < kDw / 2; ++i) { const u32x2a4 v = *T3_LDS_PTR(u32x2a4, src + 4u * d0 + 8u * i); D[2 * i] = v.x; D[2 * i + 1] = v.y; }
+            // any byte >= 27?  (b + 101) sets bit 7 exactly for b in 27..154, a byte >= 155 has it set already (a carry only adds set bits).
+            // The 56 bytes read hold the half's 54 and two of its neighbours: real input as well (stage_tile stages whole lanes).
+            uint32_t hi = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < kDw; ++i) hi |= D[i] | (D[i] + 0x65656565u);
+            if (__builtin_amdgcn_ballot_w64(live && (hi & 0x80808080u) != 0u) != 0) {       // non-canonical symbols: unpack3 reduces every digit (OLD:28-31)
+#pragma unroll
+                for (uint32_t i = 0; i < kDw; ++i) {
+                    uint32_t o = 0;
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) { const uint32_t c = (D[i] >> (8u * q)) & 0xFFu; o |= mod27(c) << (8u * q); }   // c < 256 < 512
+                    D[i] = o;
+                }
+            }
+            uint32_t R[2][7];
+#pragma unroll
+            for (uint32_t jj = 0; jj < 2; ++jj) {
+                const uint32_t B = B0 + 27u * jj;                                            // first byte of the triple in D
+                // byte k of D as the low / high half of a pair (v_perm(S0, S1): selector 0..3 = bytes of S1, 4..7 = of S0, 0x0c = zero)
+                auto pair = [&](uint32_t k1, uint32_t k2) -> u16x2 {
+                    const uint32_t sel = (k1 & 3u) | 0x0c00u | ((4u + (k2 & 3u)) << 16) | 0x0c000000u;
+                    return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(D[k2 >> 2], D[k1 >> 2], sel));
+                };
+                u16x2 P[10], Lo[10], H[9];
+#pragma unroll
+                for (uint32_t m = 0; m < 10; ++m) P[m] = m < 9u ? pair(B + 8u + 2u * m, B + 9u + 2u * m) : __builtin_bit_cast(u16x2, (D[(B + 26u) >> 2] >> (8u * ((B + 26u) & 3u))) & 0xFFu);
+                u16x2 q3[5], q9a, q9b;
+#pragma unroll
+                for (uint32_t m = 0; m < 5; ++m) { q3[m] = pk_d3(P[m]); Lo[m] = P[m] - q3[m] * (uint16_t)3; }     // c % 3 (the low half of Lo[0] is not used)
+                q9a = pk_d9(P[0]); q9b = pk_d9(P[4]);
+                {   // H[0] = (c8 % 9, c9 / 3)
+                    const u16x2 r9 = P[0] - q9a * (uint16_t)9;
+                    H[0] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(pk_bits(q3[0]), pk_bits(r9), 0x07060100u));
+                }
+#pragma unroll
+                for (uint32_t m = 1; m < 4; ++m) H[m] = q3[m];
+                H[4] = q3[4] - q9b * u16x2{0, 3};                                            // (c16 / 3, (c17 / 3) % 3)
+#pragma unroll
+                for (uint32_t m = 5; m < 10; ++m) { const u16x2 q9 = pk_d9(P[m]); if (m < 9u) H[m] = q9; Lo[m] = P[m] - q9 * (uint16_t)9; }   // c / 9, c % 9
+                uint32_t O[9];
+#pragma unroll
+                for (uint32_t m = 0; m < 9; ++m) {
+                    const u16x2 nx = __builtin_bit_cast(u16x2, __builtin_amdgcn_alignbit(pk_bits(Lo[m + 1]), pk_bits(Lo[m]), 16u));   // (Lo of c[9+2m], Lo of c[10+2m])
+                    const u16x2 Wv = m < 4u ? u16x2{9, 9} : m == 4u ? u16x2{9, 3} : u16x2{3, 3};
+                    O[m] = pk_bits(H[m] + nx * Wv);
+                }
+                // bytes: s0..s7 = c0..c7, then the nine pairs
+                auto dw = [&](uint32_t k) -> uint32_t { return (k & 3u) == 0u ? D[k >> 2] : __builtin_amdgcn_alignbyte(D[(k >> 2) + 1u], D[k >> 2], k & 3u); };
+                R[jj][0] = dw(B); R[jj][1] = dw(B + 4u);
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) R[jj][2 + i] = __builtin_amdgcn_perm(O[2 * i + 1], O[2 * i], 0x06040200u);
+                R[jj][6] = __builtin_amdgcn_perm(0u, O[8], 0x0c0c0200u);
+#pragma unroll
+                for (uint32_t i = 0; i < 7; ++i) R[jj][i] <<= (uint32_t)SH;                   // table-entry offsets (symbols <= 26: no carry between bytes)
+            }
+            // 52 bytes: the first triple's 26, then the second's at byte 26 (two bytes into dword 6)
+            uint32_t o[13];
+#pragma unroll
+            for (uint32_t i = 0; i < 6; ++i) o[i] = R[0][i];
+            o[6] = R[0][6] | (R[1][0] << 16);
+#pragma unroll
+            for (uint32_t i = 0; i < 6; ++i) o[7 + i] = __builtin_amdgcn_alignbit(R[1][i + 1], R[1][i], 16u);
+            if (live) {
+                const uint32_t d = dst + 52u * half;
+#pragma unroll
+                for (uint32_t i = 0; i < 6; ++i) *T3_LDS_WPTR(u32x2a4, d + 8u * i) = u32x2a4{o[2 * i], o[2 * i + 1]};
+                *T3_LDS_WPTR(uint32_t, d + 48u) = o[12];
+            }
+        }
+    }
+}
+template <int SH>
+__device__ __forceinline__ void convert_words_packed(const EncArgs& a, const W1Run r, uint32_t S0, uint32_t lane, uint32_t wave, uint32_t nwv) {
+    const uint32_t nuw = min(a.p1_wpp, nwv / 2u);                                            // waves per half (planner: just enough lane units)
+    if (wave >= 2u * nuw) return;
+    if (wave & 1u) convert_words_half<SH, 1>(a, r, S0, lane, wave >> 1, nuw); else convert_words_half<SH, 0>(a, r, S0, lane, wave >> 1, nuw);
+}
+
 // workgroup barrier that waits for this wave's LDS traffic only: unlike __syncthreads() it leaves the LDS-DMA prefetch
 // of the next tile (and the previous tile's global stores) in flight
 __device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -987,7 +1103,9 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 
     // first lane group whose input a tile starting at stream symbol S needs (pixels: the packed converter starts at a
     // multiple of 4 triples = 2 groups)
-    auto first_group = [](uint32_t S) -> uint32_t { return fe_px(FE) ? ((S / 13u) & ~3u) / 2u : S / GS; };
+    auto first_group = [](uint32_t S) -> uint32_t { return fe_px(FE) ? ((S / 13u) & ~3u) / 2u : ((S / 26u) & ~3u) / 2u; };   // (raw words: four word triples = two groups per lane)
+    // one past the last lane group: raw words stage whole lanes (four triples), so that no lane of the packed converter meets stale bytes
+    auto end_group = [](uint32_t S) -> uint32_t { return fe_px(FE) ? (S + GS - 1u) / GS : ((((S + 25u) / 26u) + 3u) & ~3u) / 2u; };
     // pipelined flow (input prefetch, packed converter): always in 1-D; in 2-D for pixel / RGB input (il_async != 0):
     //   il_async == 1 (rows up to 512 symbols): the tile's input covers the whole row segments it overlaps; phase 1 leaves the symbols in
     //     PRE-interleave order and a permutation pass by all waves moves them, in post-interleave order, into the stage buffer the
@@ -1011,7 +1129,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 #pragma unroll
             for (uint32_t i = 0; i < 3; ++i) {
                 T.lo[i] = R.lo[i]; T.hi[i] = R.hi[i]; T.off[i] = off;
-                const uint32_t bytes = (uint32_t)((uint64_t)((R.hi[i] + GS - 1u) / GS) * GBf - (((uint64_t)first_group(R.lo[i]) * GBf) & ~15ull));
+                const uint32_t bytes = (uint32_t)((uint64_t)end_group(R.hi[i]) * GBf - (((uint64_t)first_group(R.lo[i]) * GBf) & ~15ull));
                 if (i < R.n) off += (bytes + 1023u + 16u) & ~1023u;
             }
         }
@@ -1019,7 +1137,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     };
     auto stage_tile = [&](const TileIn& T, uint32_t stage, uint32_t w, uint32_t nw) {
 #pragma unroll
-        for (uint32_t i = 0; i < 3; ++i) if (i < T.n) stage_input<FE>(a, stage + T.off[i], first_group(T.lo[i]), (T.hi[i] + GS - 1u) / GS, lane, w, nw);
+        for (uint32_t i = 0; i < 3; ++i) if (i < T.n) stage_input<FE>(a, stage + T.off[i], first_group(T.lo[i]), end_group(T.hi[i]), lane, w, nw);
     };
     if constexpr (fast) {                                                    // prologue: first tile's input
         if (blockIdx.x < a.n_tiles) stage_tile(tile_in(blockIdx.x * TS), a.stage_off, wave, nwv);
@@ -1036,7 +1154,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     // a class's tiles are cls + NC j: j < wgc first tiles (= blockIdx), wgc <= j < 2 wgc second tiles (static too), then tickets
     // the input of tile i+1 is requested at the top of tile i into the other stage buffer, by the waves that phase 1 (pixels)
     // leaves idle: issuing the LDS-DMA costs ~400 cycles per KiB piece and would otherwise sit between the two phases
-    const uint32_t w0 = fe_px(FE) ? min(a.p1_wpp, nwv - 1u) : min((TS / GS + 2u + 63u) / 64u, nwv - 1u);   // raw words: waves that hold a lane group of the tile
+    const uint32_t w0 = fe_px(FE) ? min(a.p1_wpp, nwv - 1u) : min(2u * min(a.p1_wpp, nwv / 2u), nwv - 1u);   // waves that convert (planner: just enough lanes of four triples; raw words: two waves per lane unit)
     // Tickets are drawn by lane 0 of the LAST wave: the compiler turns the atomic into its wave-aggregated form, which reads the
     // result back at once (s_waitcnt vmcnt(0): the atomic's round trip plus the acknowledgement of the wave's stores of the
     // previous tile).  On thread 0 that stall sat in front of phase 1's conversion, on the critical path of every tile; the
@@ -1075,7 +1193,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
                 u_lo = T.lo[0];
                 if constexpr (IL == 1) convert_pixels_packed<(1 << SH), FE, false>(a, r0, r1, r2, u_lo, TS, lane, vw, nwv);   // pre-interleave order; the pass below moves them
                 else convert_pixels_packed<(1 << SH), FE, IL == 2>(a, r0, r1, r2, S0, TS, lane, vw, nwv);
-            } else convert_groups<FE, false, SH>(a, stage, S0 / GS, S0 / GS, (S0 + TS + GS - 1u) / GS, S0, TS, vw * 64u + lane, nthr);
+            } else convert_words_packed<SH>(a, w1_run(S0, S0 + TS, stage), S0, lane, vw, nwv);
 #endif
             T3_STAMP(5);                                                      // (diagnostic) this wave's conversion
             barrier_lds();                                                    // symbols complete
