@@ -773,25 +773,24 @@ __device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, const P1
             uint32_t D[9];
 #pragma unroll
             for (uint32_t i = 0; i < 9; ++i) D[i] = lds_u32(src + 4u * i);
-            uint32_t cY[12], cB[12], cR[12];
-#pragma unroll
-            for (uint32_t p = 0; p < 12; ++p) {
-                auto byte = [&](uint32_t k) -> uint32_t { return (D[k >> 2] >> (8u * (k & 3u))) & 0xFFu; };
-                rgb_px_to_comps(byte(3u * p), byte(3u * p + 1u), byte(3u * p + 2u), a.qt_off, cY[p], cB[p], cR[p]);
-            }
             // pixels past the padded end of the frame are zero TRITS (Cb + 40 = 0), which no RGB value encodes: only the frame's last lanes
             const uint64_t px0 = 3ull * t;
-            if (__builtin_amdgcn_ballot_w64(live && px0 + 12u > a.n_units_pad) != 0) {
+            const bool tail = __builtin_amdgcn_ballot_w64(live && px0 + 12u > a.n_units_pad) != 0;
+            auto byte = [&](uint32_t k) -> uint32_t { return (D[k >> 2] >> (8u * (k & 3u))) & 0xFFu; };
 #pragma unroll
-                for (uint32_t p = 0; p < 12; ++p) if (px0 + p >= a.n_units_pad) { cY[p] = 0; cB[p] = 0; cR[p] = 0; }
-            }
-#pragma unroll
-            for (uint32_t pair = 0; pair < 2; ++pair) {                           // pair 0 = triples (0, 2), pair 1 = triples (1, 3)
+            for (uint32_t pair = 0; pair < 2; ++pair) {                           // pair 0 = triples (0, 2), pair 1 = triples (1, 3): six pixels at a time (register budget)
                 u16x2 c[9];
 #pragma unroll
                 for (uint32_t m = 0; m < 3; ++m) {
                     const uint32_t pa = 3u * pair + m, pb = pa + 6u;              // pixel of the pair's first / second triple
-                    c[3 * m] = u16x2{(uint16_t)cY[pa], (uint16_t)cY[pb]}; c[3 * m + 1] = u16x2{(uint16_t)cB[pa], (uint16_t)cB[pb]}; c[3 * m + 2] = u16x2{(uint16_t)cR[pa], (uint16_t)cR[pb]};
+                    uint32_t Ya, Ba, Ra, Yb, Bb, Rb;
+                    rgb_px_to_comps(byte(3u * pa), byte(3u * pa + 1u), byte(3u * pa + 2u), a.qt_off, Ya, Ba, Ra);
+                    rgb_px_to_comps(byte(3u * pb), byte(3u * pb + 1u), byte(3u * pb + 2u), a.qt_off, Yb, Bb, Rb);
+                    if (tail) {
+                        if (px0 + pa >= a.n_units_pad) { Ya = 0; Ba = 0; Ra = 0; }
+                        if (px0 + pb >= a.n_units_pad) { Yb = 0; Bb = 0; Rb = 0; }
+                    }
+                    c[3 * m] = u16x2{(uint16_t)Ya, (uint16_t)Yb}; c[3 * m + 1] = u16x2{(uint16_t)Ba, (uint16_t)Bb}; c[3 * m + 2] = u16x2{(uint16_t)Ra, (uint16_t)Rb};
                 }
                 px3x2_to_sym13x8<SC>(c, pair ? sB : sA);
             }
@@ -1334,7 +1333,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 #endif
         T3_STAMP(2);
     }
-    if (dyn && tid == (nwv - 1u) * 64u) {
+    if (dyn && lane == 0u && wave == nwv - 1u) {                                   // (not `tid`: it would stay live, or spilled, across the whole tile loop)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (every draw was read back by its wave right away)
         if (atomicAdd(a.tile_ctr + 64u * NC, 1u) == gridDim.x - 1u) {          // ... and so has everyone else's: re-arm for the next launch
             for (uint32_t c = 0; c <= NC; ++c) __hip_atomic_store(a.tile_ctr + 64u * c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

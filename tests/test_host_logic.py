@@ -258,3 +258,31 @@ def test_host_block_codec_matches_oracle(built):
                 assert rc == int(okv[0]) and np.array_equal(mine, cw[0])
                 assert np.array_equal(outk, dk[0]) if rc else np.all(outk == 77)
     assert lib.t3hip_rs_encode_block_host(21, 0, data.ctypes.data, code.ctypes.data) == -3
+
+
+def test_no_vgpr_spills_in_hot_kernels(built):
+    """Register budget of the gfx950 code objects, read from the built objects' notes (hipcc cross-compiles without a GPU):
+    the kernels of the bench step and of the RGB / raw-word / pixel entry points at the headline code RS(26,20) carry NO spilled
+    VGPR, and no kernel of the 1-D RGB front end reloads a spilled register inside its persistent tile loop (a scratch reload is
+    followed by s_waitcnt vmcnt(0), which drains the next tile's prefetch in the middle of a phase: profiles/r02/notes.md).
+    Every instantiation's figures: `python3 profiles/kernel_resources.py`."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import kernel_resources as kr
+    ks = kr.all_kernels()
+    assert len(ks) > 100
+    must_be_clean = ["encode_kernel_k<0, 0, 6, false>", "encode_kernel_k<0, 0, 6, true>", "encode_kernel_k<1, 0, 6, false>", "encode_kernel_k<1, 0, 6, true>",
+                     "encode_kernel_k<2, 0, 6, false>", "encode_kernel_k<2, 0, 6, true>", "encode_kernel_k<2, 0, 2, false>", "encode_kernel_k<2, 0, 8, false>",
+                     "encode_kernel_uep<0, 0, false>", "encode_kernel_uep<2, 0, false>", "encode_kernel_uep<0, 1, false>", "encode_kernel_uep<2, 1, false>",
+                     "decode_fixed_px_kernel<6, false, false>", "decode_fixed_px_kernel<6, true, false>", "crc_fp4_kernel", "crc_mfma_kernel"]
+    for want in must_be_clean:
+        hit = [n for n in ks if want in n]
+        assert hit, want
+        for n in hit:
+            assert int(ks[n]["vgpr_spill_count"]) == 0, (n, ks[n])
+            assert int(ks[n]["vgpr_count"]) <= 128
+    loops = kr.loop_scratch()
+    assert len(loops) > 60
+    for n, (ld, st) in loops.items():
+        if any(w in n for w in must_be_clean) or "encode_kernel_k<2, 0, 2" in n or "encode_kernel_k<2, 0, 8, false" in n:
+            assert (ld, st) == (0, 0), (n, ld, st)
