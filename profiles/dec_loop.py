@@ -18,6 +18,8 @@ s = torch.cuda.current_stream().cuda_stream
 P = t3.ProfileID; F = t3.MODE_FIXED
 cfg = {"c2": t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=F), "words": t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=F),
        "c3": t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F),
+       "il": t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(64, 64), mode=F), "ilwide": t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(7680, 8), mode=F),
+       "uep1d": t3.make_cfg(profile=P.P3_RS26_20, uep="luma", mode=F), "k22": t3.make_cfg(profile=P.P2_RS26_22, uep=1, mode=F),
        "beacon": t3.make_cfg(profile=P.P3_RS26_20, uep=2, beacon=(64, 4, 1), mode=F)}[conf]
 words = conf == "words"
 n_raw = NPX // 2; n_enc = t3.encoded_words(n_raw, cfg)

@@ -39,15 +39,21 @@ def run(name, cfg, errors=False, words=False):
     return {"config": name, "ms": round(ms, 4), "pixels_exact": ok, "GBps": round(((9 * n_raw if words else 6 * NPX) + 9 * n_enc) / ms / 1e6, 1)}
 P = t3.ProfileID; F = t3.MODE_FIXED
 res = []
+_only = [x.lower() for x in sys.argv[1:]]                      # optional substrings: run only the rows whose name holds one of them
+_run = run
+def run(name, cfg, errors=False, words=False):
+    if _only and not any(o in name.lower() for o in _only): return None
+    return _run(name, cfg, errors, words)
 res.append(run("C2 FIXED RS(26,20) 1-D (fused decoder), clean stream", t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=F)))
-res.append(run("FIXED luma-priority UEP 1-D (two-kernel decoder), clean", t3.make_cfg(profile=P.P3_RS26_20, uep="luma", mode=F)))
-res.append(run("FIXED 2-D 64x64 RS(26,20) (two-kernel decoder), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(64, 64), mode=F)))
-res.append(run("C3 FIXED 2-D 64x64 + luma UEP (two-kernel decoder), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F)))
+res.append(run("FIXED luma-priority UEP 1-D (one-launch UEP / 2-D decoder where it applies), clean", t3.make_cfg(profile=P.P3_RS26_20, uep="luma", mode=F)))
+res.append(run("FIXED 2-D 64x64 RS(26,20) (one-launch UEP / 2-D decoder where it applies), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(64, 64), mode=F)))
+res.append(run("C3 FIXED 2-D 64x64 + luma UEP (one-launch UEP / 2-D decoder where it applies), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F)))
 res.append(run("C2 FIXED + beacon every 64 words (stepped over in the fused decoder's loads), clean", t3.make_cfg(profile=P.P3_RS26_20, uep=2, beacon=(64, 4, 1), mode=F)))
 res.append(run("C2 FIXED RS(26,20) 1-D (fused decoder), 0..3 errors per block", t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=F), errors=True))
-res.append(run("C3 FIXED 2-D 64x64 + luma UEP (two-kernel decoder), 0..2 errors per block", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F), errors=True))
+res.append(run("C3 FIXED 2-D 64x64 + luma UEP (one-launch UEP / 2-D decoder where it applies), 0..2 errors per block", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F), errors=True))
 res.append(run("C2 FIXED RS(26,20) 1-D (fused decoder) to raw words, clean stream", t3.make_cfg(profile=P.P3_RS26_20, uep=2, mode=F), words=True))
-res.append(run("C3 FIXED 2-D 64x64 + luma UEP (two-kernel decoder) to raw words, clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F), words=True))
-res.append(run("FIXED 1-D four different k per frame (two-kernel decoder), clean", t3.make_cfg(profile=P.P3_RS26_20, uep=[0, 1, 2, 3, 0, 1, 2, 3, 0], mode=F)))
-res.append(run("FIXED 2-D wide rows 7680x8 RS(26,20) (two-kernel decoder), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(7680, 8), mode=F)))
+res.append(run("C3 FIXED 2-D 64x64 + luma UEP (one-launch UEP / 2-D decoder where it applies) to raw words, clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64), mode=F), words=True))
+res.append(run("FIXED 1-D four different k per frame (one-launch UEP / 2-D decoder where it applies), clean", t3.make_cfg(profile=P.P3_RS26_20, uep=[0, 1, 2, 3, 0, 1, 2, 3, 0], mode=F)))
+res.append(run("FIXED 2-D wide rows 7680x8 RS(26,20) (one-launch UEP / 2-D decoder where it applies), clean", t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(7680, 8), mode=F)))
+res = [r for r in res if r is not None]
 print(json.dumps(res, indent=1))

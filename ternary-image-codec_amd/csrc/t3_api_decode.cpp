@@ -233,6 +233,109 @@ int occupancy_of(const void* fn, int threads, uint32_t lds_bytes, int* out) {
     *out = it->second; return T3_OK;
 }
 
+// One-launch FIXED decode for per-band k (two codes at most) and / or the 2-D interleave, pixels out (t3_decode_uep.hip).  Returns T3_OK
+// after launching, 1 if not applicable (the two-kernel path then takes the frame).
+int decode_fixed_uep(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_syms, const t3_cfg& cfg, const t3_layout& L, const ScrCycle& sc,
+                     void* d_out, uint64_t units, uint32_t* d_fail, hipStream_t s) {
+    if (L.n_raw_words == 0 || L.n_sym + (1u << 20) >= (1ull << 32) || body_bytes + hdr_syms >= (1ull << 32)) return 1;
+    if (getenv("T3HIP_GENERIC_DECODE") != nullptr || getenv("T3HIP_TWO_KERNEL_DECODE") != nullptr) return 1;
+    if (body_bytes >= (1ull << 28)) return 1;                              // the kernel packs a block's byte offset into 28 bits
+    const bool il = L.interleave2d != 0 && cfg.tile_w > 1;                 // (rows of one symbol: the map is the identity)
+    DecUepArgs a; memset(&a, 0, sizeof a);
+    int gk[kUepMaxGrp]; uint32_t gn[kUepMaxGrp] = {0, 0}; int ng = 0;
+    for (int b = 0; b < 9; ++b) {
+        int g = -1;
+        for (int q = 0; q < ng; ++q) if (gk[q] == L.band_k[b]) g = q;
+        if (g < 0) { if (ng == kUepMaxGrp) return 1; g = ng++; gk[g] = L.band_k[b]; }
+        a.grp[g].bands[gn[g]++] = (uint8_t)b;
+    }
+    if (ng == 2 && gk[0] > gk[1]) {                                        // group 0 = the code with more parity (the kernel is instantiated for r0 >= r1)
+        std::swap(gk[0], gk[1]); std::swap(gn[0], gn[1]);
+        uint8_t t[12]; memcpy(t, a.grp[0].bands, 12); memcpy(a.grp[0].bands, a.grp[1].bands, 12); memcpy(a.grp[1].bands, t, 12);
+    }
+    if (il) {
+        const uint64_t A = (uint64_t)cfg.tile_w * cfg.tile_h;
+        if (cfg.tile_w % 4u || (A % 4u && A < L.n_sym) || L.n_sym % 4u) return 1;      // the in-place row reversal works on dword granules
+        a.il_on = 1; a.il_w = cfg.tile_w; a.il_A = (uint32_t)std::min<uint64_t>(A, L.n_sym);
+        if (a.il_A < 2 || a.il_w < 2) return 1;
+        a.div_A = to_dev(fastdiv(a.il_A)); a.div_w = to_dev(fastdiv(a.il_w));
+    }
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    uint32_t lcm = 1;
+    for (int g = 0; g < ng; ++g) { const int rc = ensure_fx_tables(gk[g]); if (rc) return rc; uint32_t x = lcm, y = (uint32_t)gk[g]; while (y) { const uint32_t t = x % y; x = y; y = t; } lcm = lcm / x * (uint32_t)gk[g]; }
+    // LDS: [hdr][fold 512][T16 1024][FMA][A operands][pattern rows 192][records 128][Y0][Y1][Q0][Q1] within 42 x 1280 B (three workgroups per CU)
+    const uint32_t fixed_bytes = (uint32_t)kFx2TPx + 3u * 27u * 4u * 16u + 19696u + 3328u + 192u + 128u;   // (one A operand: group 0's evaluation matrix holds group 1's)
+    const uint32_t budget = 42u * 1280u;
+    uint32_t best_m = 0;
+    for (uint32_t m = 1; 9u * lcm * m <= 12000u; ++m) {
+        const uint32_t Lq = lcm * m, TS = 9u * Lq;
+        if (TS % 4u) continue;
+        uint32_t pairs = 0;
+        for (int g = 0; g < ng; ++g) { const uint32_t items = gn[g] * (Lq / (uint32_t)gk[g]); if (Lq / (uint32_t)gk[g] < 2u || Lq / (uint32_t)gk[g] >= 2048u) { pairs = 99; break; } pairs += ((items + 31u) / 32u + 1u) / 2u; }
+        if (pairs > 8u) break;
+        const uint32_t ybytes = (TS + 16u + 15u) & ~15u;
+        if (fixed_bytes + 2u * ybytes + 2u * 10u * 96u + 64u > budget) break;            // (at least 96 queue entries per buffer)
+        best_m = m;
+    }
+    if (!best_m) return 1;
+    const uint32_t Lq = lcm * best_m;
+    a.TS = 9u * Lq; a.n_sym = (uint32_t)L.n_sym; a.hdr_syms = hdr_syms; a.n_grp = (uint32_t)ng;
+    a.in = body; a.in_bytes = body_bytes; a.out = d_out; a.n_units = units; a.fail = d_fail;
+    a.ttab = d_synd_T16; a.small = d_fx2_small; a.fma = d_fma;
+    a.fma_off = (uint32_t)kFx2TPx + 3u * 27u * 4u * 16u;
+    uint32_t off = a.fma_off + 19696u;
+    uint64_t tiles = 0; uint32_t items_all = 0;
+    for (int g = 0; g < ng; ++g) {
+        auto& G = a.grp[g]; const int ki = k_index(gk[g]);
+        G.r = 26u - (uint32_t)gk[g]; G.nb = Lq / (uint32_t)gk[g]; G.n_items = gn[g] * G.nb; G.div_nb = to_dev(fastdiv(G.nb));
+        G.afrag = d_synd_afrag[ki]; G.roots = d_roots[ki];
+        if (g == 0) { G.af_off = off; off += 3328u; } else G.af_off = a.grp[0].af_off;
+        items_all += G.n_items;
+        for (uint32_t i = 0; i < gn[g]; ++i) tiles = std::max<uint64_t>(tiles, (L.band_blocks[G.bands[i]] + G.nb - 1) / G.nb);
+    }
+    a.n_tiles = (uint32_t)tiles;
+    a.pat_off = off; off += 192u; a.rec_off = off; off += 128u;
+    const uint32_t ybytes = (a.TS + 16u + 15u) & ~15u;
+    a.y_off = off; a.y_stride = ybytes; off += 2u * ybytes;
+    const uint32_t q_entries = std::min<uint32_t>((budget - 64u - off) / 20u, items_all);  // per buffer, split over the groups by their share of the blocks (64: roundings below)
+    uint32_t qrel = 0;
+    for (int g = 0; g < ng; ++g) { auto& G = a.grp[g]; G.q_cap = std::max<uint32_t>(8u, (uint32_t)((uint64_t)q_entries * G.n_items / items_all) & ~3u); G.q_rel = qrel; qrel += 10u * G.q_cap; }
+    a.q_off = off; a.q_stride = (qrel + 15u) & ~15u; off += 2u * a.q_stride;
+    a.lds_bytes = off + 16u;
+    if (a.lds_bytes > 160u * 1024u) return 1;
+    {   // (wave, pass) pairs of sets: pair p -> wave p % 4, pass p / 4
+        for (int i = 0; i < 8; ++i) a.pair_tab[i] = 0xFFFFFFFFu;
+        uint32_t p = 0;
+        for (int g = 0; g < ng; ++g) for (uint32_t it0 = 0; it0 < a.grp[g].n_items; it0 += 64u, ++p) a.pair_tab[2u * (p % 4u) + p / 4u] = (uint32_t)g | it0 << 8;
+    }
+    for (int b = 0; b < 9; ++b) { a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b]; a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6); }
+    {
+        uint8_t rows[12][16]; memset(rows, 0, sizeof rows);
+        for (int r = 0; r < 11; ++r) for (int q = 0; q < 13; ++q) rows[r][q] = (uint8_t)(27u * sc.cyc[(r + q) % 6]);
+        for (int q = 0; q < 13; ++q) rows[11][q] = (uint8_t)(27u * (q == 0 ? sc.pre[0] : q == 1 ? sc.pre[1] : sc.cyc[(4 + q) % 6]));
+        memcpy(a.pat, rows, sizeof rows);
+    }
+    void* d_e; int rc = api_scratch(3, L.n_sym + 64, &d_e, s); if (rc) return rc;
+    a.edge = (uint8_t*)d_e;
+    const void* fn = nullptr;
+    {
+        const int ra = 26 - gk[0], rb = ng == 2 ? 26 - gk[1] : ra;
+#define T3_UEP(A, B) if (ra == A && rb == B) fn = (const void*)decode_uep_px_kernel<A, B>;
+        T3_UEP(2, 2) T3_UEP(4, 4) T3_UEP(6, 6) T3_UEP(8, 8) T3_UEP(4, 2) T3_UEP(6, 2) T3_UEP(6, 4) T3_UEP(8, 2) T3_UEP(8, 4) T3_UEP(8, 6)
+#undef T3_UEP
+        if (!fn) return 1;
+    }
+    int occ = 1; rc = occupancy_of(fn, 512, a.lds_bytes, &occ); if (rc) return rc;
+    occ = std::max(1, std::min<int>(occ, (int)(128u / ((a.lds_bytes + 1279u) / 1280u))));
+    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(a.n_tiles, (uint32_t)(api_n_cu() * occ)));
+    static const bool st = getenv("T3HIP_STATIC_TILES") != nullptr;
+    a.tile_ctr = st ? nullptr : api_ticket_counters(s, 2); a.n_classes = std::min<uint32_t>(8u, grid);
+    void* args[] = {(void*)&a};
+    HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(512), args, a.lds_bytes, s));
+    HIPCHK(hipLaunchKernel((const void*)uep_edge_kernel, dim3((3u * a.n_tiles + 1u + 255u) / 256u), dim3(256), args, 0, s));
+    return T3_OK;
+}
+
 // Two-kernel FIXED decode (t3_decode_stream.hip): any per-band k, 1-D or 2-D.  Returns T3_OK after launching, 1 if not applicable.
 int decode_fixed_stream(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_syms, const t3_cfg& cfg, const t3_layout& L, const ScrCycle& sc,
                         void* d_out, uint64_t units, int to_pixels, uint32_t* d_fail, hipStream_t s) {
@@ -351,6 +454,7 @@ int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_r
                 }
                 if (!bcn_ok) frc = decode_fixed_fused(body, body_bytes, hs, L, sc, d_out, funits, to_pixels, d_fail, s);
                 if (frc == 1 && want_rgb) return 1;
+                if (frc == 1 && to_pixels == 1) frc = decode_fixed_uep(body, body_bytes, hs, cfg, L, sc, d_out, funits, d_fail, s);
                 if (frc == 1) frc = decode_fixed_stream(body, body_bytes, hs, cfg, L, sc, d_out, funits, to_pixels, d_fail, s);
             }
             if (frc == T3_OK) { *n_out = funits; return T3_OK; }

@@ -123,6 +123,28 @@ struct DecFx2Args {
     uint64_t* dbg;                             // diagnostic stamp builds only (T3_DEC_STAMPS); null in the product
 };
 
+// One-launch FIXED decoder for per-band k (two codes) and / or the 2-D interleave, pixels out (t3_decode_uep.hip): the block stages of the
+// uniform-k kernel with the bands grouped by k, odd row pieces reversed in LDS, whole pixel triples of the tile's pre-interleave runs
+// emitted from LDS and the triples the runs' ends cut through completed by uep_edge_kernel from a sparse scratch.
+// LDS: [hdr 0][fold tables 512][T16 1024][FMA][A operand per group][pattern rows][group records, pair table][Y0][Y1][Q0][Q1]
+constexpr int kUepMaxGrp = 2;
+struct DecUepArgs {
+    const uint8_t* in; uint64_t in_bytes;      // coded body (hdr_syms symbols of header in front)
+    void* out; uint64_t n_units;               // pixels
+    uint32_t* fail;
+    const uint32_t* ttab; const uint8_t* small; const uint8_t* fma; uint32_t fma_off;
+    struct Grp { uint32_t r, nb, n_items, af_off, q_rel, q_cap; DevDiv div_nb; const uint32_t* afrag; const uint32_t* roots; uint8_t bands[12]; } grp[kUepMaxGrp];   // q_rel: the group's queue inside a buffer's queue area
+    uint32_t n_grp;
+    uint32_t pair_tab[8];                      // slot 2 wave + pass -> group | first item << 8 (two sets of 32 blocks of one group); 0xFFFFFFFF: none
+    uint32_t TS, n_tiles, n_sym, hdr_syms;
+    uint32_t band_blocks[9]; uint64_t band_body_off[9]; uint32_t band_boff6[9];
+    uint32_t pat[48], pat_off, rec_off;
+    uint32_t y_off, y_stride, q_off, q_stride, lds_bytes;
+    uint32_t* tile_ctr; uint32_t n_classes;
+    uint32_t il_on, il_w, il_A; DevDiv div_A, div_w;
+    uint8_t* edge;                             // global scratch, n_sym bytes, written sparsely: the symbols of the triples the runs' ends cut through
+};
+
 // Two-kernel FIXED decoder for the framings the fully fused kernel does not take (mixed k, 2-D interleave; a beacon is
 // stripped by a pre-pass): D1-D4 as above with the bands grouped by k (whole waves per group), corrected data symbols to a
 // stream-ordered scratch; then symbols [through the de-interleave map] -> units.  (t3_decode_stream.hip)
@@ -160,6 +182,8 @@ __global__ void dec_gather_rs_kernel(const DecArgs a);
 template <int R, bool BCN> __global__ void decode_fixed_kernel(const DecFx2Args a);        // BCN: beacon symbols stepped over in the loads
 template <int R, bool RGB, bool BCN> __global__ void decode_fixed_px_kernel(const DecFx2Args a);
 __global__ void decode_stream_kernel(const DecStArgs a);
+template <int RA, int RB> __global__ void decode_uep_px_kernel(const DecUepArgs a);    // RA >= RB: r of group 0 / 1
+__global__ void uep_edge_kernel(const DecUepArgs a);
 template <bool TO_PIXELS> __global__ void emit_stream_kernel(const EmitStArgs a);
 __global__ void debeacon_kernel(const DebeaconArgs a);
 __global__ void dec_emit_kernel(const EmitArgs a);

@@ -77,10 +77,14 @@ __device__ __forceinline__ Blk fx2_block(const Geo g, const uint32_t off, const 
 // the caller (prefetched ahead).  The three mod-3 fold tables M_t[x] = 3^t ((x - 81) mod 3) are 160 B each.
 // TCOP bank copies of the T table at LDS offset TBASE (32: conflict-free; 16: lanes n and n + 16 share a copy, two-way conflicts,
 // half the space); MT: LDS offset of the fold tables (a compile-time constant, so that it rides in the instruction's offset field).
-template <int R, uint32_t TCOP, uint32_t TBASE, uint32_t MT, uint32_t SMB = 0>
+// RM >= R: the A operand at af_off is the evaluation matrix of RS(26, 26 - RM).  The roots of a code with fewer parity symbols are the
+// first ones of a code with more (alpha^1 .. alpha^r), so one operand serves both codes of a two-code frame (t3_decode_uep.hip):
+// RM syndromes are folded, the first R of them returned.
+template <int R, uint32_t TCOP, uint32_t TBASE, uint32_t MT, uint32_t SMB = 0, int RM = R>
 __device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], const uint32_t lane, const uint32_t af_off, const uint32_t pat_off) {
     constexpr uint32_t mt = MT;
-    constexpr uint32_t K = 26 - R, H = R / 2;
+    constexpr uint32_t K = 26 - R, H = RM / 2, HB = R / 2;
+    static_assert(RM >= R, "matrix of the code with more parity");
     const uint32_t n = lane & 31u, h = lane >> 5;
     // symbol q of this lane (position 13 h + q) = byte q of W: h = 1 starts at byte 3 of its load
     uint32_t W[4];
@@ -173,6 +177,11 @@ __device__ __forceinline__ Synd fx2_set(const Blk& b, const uint32_t (&Lw)[4], c
     }
     const auto sw = __builtin_amdgcn_permlane32_swap(Pown, Pown, false, false);    // [0]: every lane sees the h = 0 half, [1]: the h = 1 half
     Synd r; r.lo = sw[0]; r.hi = sw[1];
+    if constexpr (RM != R) {                                                       // S_0 .. S_{R-1} of the RM folded: bytes of sw[0] | sw[1] << 8 H
+        const uint64_t V = (uint64_t)sw[0] | (uint64_t)sw[1] << (8u * H);
+        constexpr uint64_t M = (1ull << (8u * HB)) - 1ull;
+        r.lo = (uint32_t)(V & M); r.hi = (uint32_t)((V >> (8u * HB)) & M);
+    }
     return r;
 }
 
@@ -212,12 +221,15 @@ __device__ __forceinline__ uint32_t fx2_correct(const uint32_t* S, Fix& fx, cons
     uint32_t Sx[R];                                                                // FMA + 729 S_j
 #pragma unroll
     for (int j = 0; j < R; ++j) Sx[j] = __umul24(S[j], 729u) + FMA;
-    // sigma_1..T (plain and x 27) and x^m B (x 27) as in fx_correct (B unscaled, the division kept in the scalar -1 / d_old)
-    uint32_t sg[T + 1], sg27[T + 1], bx27[T + 1];
+    // sigma_1..T (plain and x 27) and bs = -x^m B / d_old (x 27).  Round 3: the update vector is kept ALREADY divided by the
+    // discrepancy it stems from, so sigma += d * bs is one table level behind d (round 2 kept B unscaled and first formed the scalar
+    // -d / d_old: one more dependent read in each of the six iterations of a chain that is bound by its length); a length change
+    // rescales the old sigma by -1 / d with T - 1 reads that nobody waits for.  The field elements are the same.
+    uint32_t sg[T + 1], sg27[T + 1], bs27[T + 1];
 #pragma unroll
-    for (int i = 0; i <= T; ++i) { sg[i] = 0; sg27[i] = 0; bx27[i] = 0; }
-    sg[0] = 1; sg27[0] = 27; bx27[1] = 27;
-    uint32_t L = 0, nbx = FMA + 2u * 729u;                                        // FMA + 729 (-1 / d_old), d_old = 1
+    for (int i = 0; i <= T; ++i) { sg[i] = 0; sg27[i] = 0; bs27[i] = 0; }
+    sg[0] = 1; sg27[0] = 27; bs27[1] = 27u * 2u;                                    // B = 1, d_old = 1: bs = -x
+    uint32_t L = 0;
     bool over = false;
 #pragma unroll
     for (int n = 0; n < R; ++n) {
@@ -225,17 +237,22 @@ __device__ __forceinline__ uint32_t fx2_correct(const uint32_t* S, Fix& fx, cons
 #pragma unroll
         for (int i = 1; i <= T; ++i) if (i <= n) d = tab(Sx[n - i] + sg27[i] + d);   // d += sigma_i S_{n-i}
         const bool upd = d != 0 && 2u * L <= (uint32_t)n;
-        const uint32_t nc = tab(nbx + 27u * d);                                     // -(d / d_old)
-        const uint32_t ncx = __umul24(nc, 729u) + FMA;
+        const uint32_t dx = __umul24(d, 729u) + FMA;
         uint32_t old27[T + 1];
 #pragma unroll
         for (int i = 0; i <= T; ++i) old27[i] = sg27[i];
 #pragma unroll
-        for (int i = 1; i <= T; ++i) if (i <= n + 1) { sg[i] = tab(ncx + bx27[i] + sg[i]); sg27[i] = 27u * sg[i]; }   // sigma - (d / d_old) x^m B
-        if (upd) { L = (uint32_t)n + 1u - L; nbx = __umul24(l8(SM + kFx2NINV + d), 729u) + FMA; over = over || L > (uint32_t)T; }
+        for (int i = 1; i <= T; ++i) if (i <= n + 1) { sg[i] = tab(dx + bs27[i] + sg[i]); sg27[i] = 27u * sg[i]; }   // sigma + d bs
+        // the next update vector: x bs, or after a length change -x sigma_old / d
+        const uint32_t ninv = l8(SM + kFx2NINV + d), nix = __umul24(ninv, 729u) + FMA;
+        uint32_t nb27[T + 1];
+        nb27[0] = 0; nb27[1] = 27u * ninv;
 #pragma unroll
-        for (int i = T; i >= 1; --i) bx27[i] = upd ? old27[i - 1] : bx27[i - 1];
-        bx27[0] = 0;
+        for (int i = 2; i <= T; ++i) nb27[i] = (i <= n + 1) ? 27u * tab(nix + old27[i - 1]) : 0u;                  // (sigma_old has degree <= n)
+        if (upd) { L = (uint32_t)n + 1u - L; over = over || L > (uint32_t)T; }
+#pragma unroll
+        for (int i = T; i >= 1; --i) bs27[i] = upd ? nb27[i] : bs27[i - 1];
+        bs27[0] = 0;
     }
     uint32_t deg = 0;
 #pragma unroll
@@ -377,7 +394,9 @@ __device__ __forceinline__ void fx2_own_blocks(const uint32_t* __restrict__ root
     if (bal != 0ull) {                                                              // wave-aggregated append: one LDS atomic per wave
         const uint32_t cnt = (uint32_t)__popcll(bal), first = (uint32_t)__builtin_ctzll(bal);
         uint32_t base = 0;
-        if (lane == first) base = __hip_atomic_fetch_add((uint32_t*)__builtin_assume_aligned(lds + cnt_addr, 4), cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (the lane number is rebuilt here: as a value kept from the kernel's first lines it gets spilled, and its reload waits for every
+        // load in flight)
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == first) base = __hip_atomic_fetch_add((uint32_t*)__builtin_assume_aligned(lds + cnt_addr, 4), cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         base = __builtin_amdgcn_readlane(base, (int)first);
         if (flagged) {
             const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
