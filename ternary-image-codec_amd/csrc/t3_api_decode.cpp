@@ -255,7 +255,7 @@ int decode_fixed_uep(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_syms
     }
     if (il) {
         const uint64_t A = (uint64_t)cfg.tile_w * cfg.tile_h;
-        if (cfg.tile_w % 4u || (A % 4u && A < L.n_sym) || L.n_sym % 4u) return 1;      // the in-place row reversal works on dword granules
+        if (cfg.tile_w % 4u || (A % 4u && A < L.n_sym)) return 1;                       // the in-place row reversal works on dword granules (the stream's last row: bytes)
         a.il_on = 1; a.il_w = cfg.tile_w; a.il_A = (uint32_t)std::min<uint64_t>(A, L.n_sym);
         if (a.il_A < 2 || a.il_w < 2) return 1;
         a.div_A = to_dev(fastdiv(a.il_A)); a.div_w = to_dev(fastdiv(a.il_w));

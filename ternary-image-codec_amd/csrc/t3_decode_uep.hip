@@ -14,8 +14,8 @@
 //     (one lane = four triples, funnel-shifted to the run's byte alignment).  The few symbols of the triples a run's ends cut through
 //     (< 13 each side) go to a sparse scratch at their stream positions, and uep_edge_kernel -- one lane per run start -- converts those
 //     triples afterwards: a few hundred bytes per tile instead of the whole frame.
-// Restrictions (the host falls back to the two-kernel path): at most two codes; rows, chunk area and stream length multiples of 4
-// symbols in 2-D; pixels out (no raw-word output, no fused RGB).
+// Restrictions (the host falls back to the two-kernel path): at most two codes; rows and chunk area multiples of 4 symbols in 2-D (the
+// stream's last, shorter row may be anything); pixels out (no raw-word output, no fused RGB).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -272,6 +272,10 @@ __global__ __launch_bounds__(512, 6) void decode_uep_px_kernel(const DecUepArgs 
                         const RowG rg = row_of(a, v);
                         if (!rg.odd) continue;
                         const uint32_t lo = max(rg.start, S0), hi = min(rg.start + rg.len, E);
+                        if ((hi - lo) & 3u) {                                            // the stream's last row, when it is not whole dwords: one lane, byte by byte
+                            if (v == lo) for (uint32_t i = lo, j = hi - 1u; i < j; ++i, --j) { const uint32_t x = l8(y_off + (i - S0)); *T3_LP(uint8_t, y_off + (i - S0)) = (uint8_t)l8(y_off + (j - S0)); *T3_LP(uint8_t, y_off + (j - S0)) = (uint8_t)x; }
+                            continue;
+                        }
                         const uint32_t v2 = lo + hi - 4u - v;                            // the mirrored granule inside the piece
                         if (v2 < v) continue;                                            // (its partner does the swap)
                         const uint32_t x = *T3_LP(const uint32_t, y_off + (v - S0)), y = *T3_LP(const uint32_t, y_off + (v2 - S0));

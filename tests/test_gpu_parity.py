@@ -974,3 +974,57 @@ def test_shutdown_and_reinit(t3, orc, gpu):
     ok, enc2 = gpu.encode_frame(px, cfg); assert ok and np.array_equal(enc, enc2)
     ok, back = gpu.decode_frame(enc2, gpu.DecoderContext(mode=1)); assert ok and np.array_equal(back[:5000], px)
     assert t3.crc32(np.arange(300000, dtype=np.uint8)) == crc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(profile=1, uep="luma"), dict(profile=4, uep="luma", tile=(64, 64)), dict(profile=4, uep=2, tile=(64, 64)),
+                                dict(profile=4, uep=[3, 1, 1, 3, 1, 1, 3, 1, 1], tile=(128, 3)), dict(profile=4, uep=0, tile=(7680, 8)),
+                                dict(profile=4, uep=[2, 0, 2, 0, 2, 0, 2, 0, 2], tile=(20, 20)), dict(profile=4, uep="luma", tile=(4112, 7)),
+                                dict(profile=4, uep=1, tile=(12, 1))])
+def test_uep_one_launch_decoder(gpu, orc, kw):
+    """decode_uep_px_kernel + uep_edge_kernel (round 3: per-band k and / or 2-D in ONE launch, the tile's symbols never leave LDS) against
+    the original pixels, the oracle's restatement of the FIXED decoder and the two-kernel path (T3HIP_TWO_KERNEL_DECODE=1) on corrupted
+    streams: sizes of under one tile up to many, pixel counts whose last triple / last row / last block are ragged, two codes in either
+    order, narrow, odd-height and very wide rows, 0..t errors in every block; one uncorrectable block is reported by both."""
+    rng = np.random.default_rng(zlib.crc32(repr(sorted(kw.items())).encode()) & 0xFFFF)
+    cfg, ocfg = both(gpu, kw, mode=1)
+    for n in (2, 54, 1210, 6 * 4399, 200_004, 600_000 + 6 * 7):
+        L = gpu.plan((n + 1) // 2, cfg)
+        px = rand_pixels(rng, n)
+        ok, enc = gpu.encode_frame(px, cfg); assert ok
+        bad = np.asarray(orc.inject_errors(enc, L.header_syms, L.body_syms // 26, 1000 + n % 97, (26 - max(L.band_k)) // 2)).reshape(-1, 9)
+        padded = np.zeros(2 * ((n + 1) // 2), ol.PIXEL_DT); padded[:n] = px
+        outs = {}
+        for two in (False, True):
+            if two: os.environ["T3HIP_TWO_KERNEL_DECODE"] = "1"
+            try:
+                okp, back = gpu.decode_frame(bad, gpu.DecoderContext(mode=1))
+            finally:
+                os.environ.pop("T3HIP_TWO_KERNEL_DECODE", None)
+            outs[two] = (okp, np.asarray(back).view(np.uint8).reshape(-1).copy())
+        assert outs[False][0] and outs[True][0], (kw, n)
+        assert np.array_equal(outs[False][1], padded.view(np.uint8).reshape(-1)), (kw, n)
+        assert np.array_equal(outs[False][1], outs[True][1]), (kw, n)
+        if n <= 30_000:
+            rc, want = orc.decode_frame(bad, ol.make_cfg(mode=1))
+            assert rc == 0 and np.array_equal(np.asarray(want).view(np.uint8).reshape(-1), outs[False][1]), (kw, n)
+    # t + 1 errors in one block of the weakest band's code: uncorrectable, or (rarely; always for t = 1) miscorrected -- whichever the code
+    # gives, both paths and the oracle's restatement of decode_block's FIXED flavour must agree on the verdict
+    n = 60_006
+    L = gpu.plan(n // 2, cfg)
+    ok, enc = gpu.encode_frame(rand_pixels(rng, n), cfg); assert ok
+    flat = np.ascontiguousarray(enc).reshape(-1).copy()
+    b = int(np.argmax(L.band_k)); t = (26 - int(L.band_k[b])) // 2
+    base = L.header_syms + int(L.band_body_off[b]) + 26 * 17
+    for i in range(t + 1):
+        flat[base + 2 * i] = (flat[base + 2 * i] + 1 + 3 * i) % 27
+    rc, _ = orc.decode_frame(flat.reshape(-1, 9), ol.make_cfg(mode=1))
+    verdicts = []
+    for two in (False, True):
+        if two: os.environ["T3HIP_TWO_KERNEL_DECODE"] = "1"
+        try:
+            okp, _ = gpu.decode_frame(flat.reshape(-1, 9), gpu.DecoderContext(mode=1))
+        finally:
+            os.environ.pop("T3HIP_TWO_KERNEL_DECODE", None)
+        verdicts.append(bool(okp))
+    assert verdicts[0] == verdicts[1] == (rc == 0), (kw, verdicts, rc)      # (short codes: the spheres of radius t cover 40 % of the space for r = 4)
