@@ -7,6 +7,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <string>
@@ -33,6 +35,8 @@ struct Ctx {
     std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> sbuf;              // slots 2, 3: intermediates of the *_dev entry points, one set per caller stream
     uint32_t* d_ctr = nullptr; std::map<std::pair<hipStream_t, int>, uint32_t> ctr_slot;   // tile-ticket counters, one set per (stream, kernel kind) in use
     uint32_t* d_flag = nullptr;                         // failure counter for the synchronous decode entry points
+    hipStream_t stream2 = nullptr;                      // the download side of the pipelined host entry points (created on first use)
+    std::vector<hipEvent_t> chunk_ev;                   // ... and their per-chunk events
     std::string hip_err;
     std::mutex mu;
     // The host-buffer entry points share one stream and two scratch slots: each of them holds this for its whole upload ->
@@ -550,6 +554,9 @@ static void ctx_teardown(Ctx* c) {                       // also of a partly bui
     if (c->slot[47]) (void)hipFree(c->slot[47]);          // chroma quantiser table of the fused RGB front end (rgb_quant_table)
     for (void*& p : c->slot) p = nullptr;
     if (c->d_ctr) { (void)hipFree(c->d_ctr); c->d_ctr = nullptr; } c->ctr_slot.clear();
+    for (hipEvent_t e : c->chunk_ev) (void)hipEventDestroy(e);
+    c->chunk_ev.clear();
+    if (c->stream2) { (void)hipStreamDestroy(c->stream2); c->stream2 = nullptr; }
     if (c->d_tab) (void)hipFree(c->d_tab); if (c->d_flag) (void)hipFree(c->d_flag); if (c->stream) (void)hipStreamDestroy(c->stream);
     c->d_tab = nullptr; c->d_flag = nullptr; c->stream = nullptr;
     c->ready = false; c->dev = -1;
@@ -705,6 +712,104 @@ int t3hip_unpack_words(const void* words, uint64_t n_words, void* px) {
     HIPCHK(hipMemcpyAsync(px, dout, n_words * 12, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream)); return T3_OK;
 }
+// Pipelined host entry (round 3): the frame crosses PCIe once in each direction, and the two directions overlap.  Tiles are independent
+// (SURVEY 5), and a range of whole tiles that starts on a pixel-triple / word-triple boundary at a 16-byte aligned input offset is a
+// frame of its own to the kernel -- same kernel, shifted pointers and band offsets, no tile-range logic in the hot loop.  The caller's
+// thread uploads chunk c and launches it; a helper thread downloads the nine band runs of chunk c - 1 meanwhile (pageable memory: a HIP
+// copy occupies its calling thread, so the two directions need two threads; measured on the box, profiles/exp/pcie_probe.cpp: 3.5 ms up
+// + 3.3 ms down one after the other, 4.0-4.2 ms both at once).  One k on all bands, 1-D, no beacon; anything else: the serial path (1).
+static int encode_host_pipelined(int fe, const void* in, uint64_t n_units, const t3_cfg* cfg, void* out, const t3_layout& L, void* di, void* dout) {
+    if (fe == FE_RGB || L.interleave2d || L.beacon_on || cfg->profile == T3_RAW_MODE || getenv("T3HIP_SERIAL_HOST") != nullptr) return 1;
+    for (int b = 1; b < 9; ++b) if (L.band_k[b] != L.band_k[0]) return 1;
+    const uint64_t n_raw = fe == FE_PIXELS ? (n_units + 1) / 2 : n_units;
+    EncLaunch e0; const LutImage* lut;
+    uint8_t hdr[96]; memset(hdr, 0, sizeof hdr);
+    uint32_t hs;
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        int rc = get_mfma_lut(L.band_k[0], cfg->mode, &lut); if (rc) return rc;
+        if (!plan_enc_group(L, *cfg, 0x1FF, fe, *lut, e0) || !e0.rsel || e0.block > 512) return 1;
+        hs = (uint32_t)header_encode(*cfg, n_raw, hdr);
+    }
+    const uint32_t TS = 9u * e0.a.Lq, unit_syms = fe == FE_PIXELS ? 104u : 416u;     // chunk starts: whole triples at 16-byte aligned input offsets
+    uint32_t G = unit_syms; { uint32_t x = TS, y = unit_syms; while (y) { const uint32_t t = x % y; x = y; y = t; } G = unit_syms / x; }   // tiles per alignment unit
+    const uint32_t n_tiles = e0.a.n_tiles;
+    static const uint32_t want_env = getenv("T3HIP_HOST_CHUNKS") ? (uint32_t)atoi(getenv("T3HIP_HOST_CHUNKS")) : 0u;   // measurement knob
+    // chunks: fill / drain of the pipeline against per-copy overheads.  The nine band runs of a chunk go down as ONE strided copy when the
+    // bands are equally long and everything is 4-byte aligned (COMPAT: 52 header symbols; measured 4.70 ms per 8K frame with 12 chunks);
+    // a strided copy at 2-byte alignment (FIXED: 90 header symbols) falls off a cliff (13 ms), so there: nine plain copies, 6 chunks (5.1 ms)
+    bool even_bands = true; for (int b = 1; b < 9; ++b) even_bands = even_bands && L.band_blocks[b] == L.band_blocks[0];
+    const bool strided = even_bands && hs % 4u == 0 && (26ull * L.band_blocks[0]) % 4u == 0 && getenv("T3HIP_NO_2D_COPY") == nullptr;
+    const uint32_t want = want_env ? want_env : strided ? 12u : 6u;
+    uint32_t per = (n_tiles / want + G - 1u) / G * G;
+    if (per == 0 || n_tiles < 4u * G) return 1;                                      // small frames: the serial path
+    const uint32_t n_chunks = (n_tiles + per - 1u) / per;
+    if (!g.stream2) HIPCHK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
+    while (g.chunk_ev.size() < n_chunks) { hipEvent_t ev; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); g.chunk_ev.push_back(ev); }
+    const uint32_t UB = fe == FE_PIXELS ? 6u : 9u;
+    const uint64_t in_bytes = n_units * UB;
+    std::atomic<uint32_t> launched{0}; std::atomic<int> abort_dl{0};
+    hipError_t dl_err = hipSuccess;
+    const int dev = g.dev; hipStream_t s2 = g.stream2; const std::vector<hipEvent_t>& evs = g.chunk_ev;
+    uint8_t* const ho = (uint8_t*)out; const uint8_t* const dob = (const uint8_t*)dout;
+    const uint32_t nb = e0.a.nb_uniform;
+    std::thread dl([&] {
+        if (hipSetDevice(dev) != hipSuccess) { dl_err = hipErrorInvalidDevice; return; }
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            while (launched.load(std::memory_order_acquire) <= c) { if (abort_dl.load()) return; std::this_thread::yield(); }
+            hipError_t er = hipEventSynchronize(evs[c]);
+            const uint64_t t0 = (uint64_t)c * per, t1 = std::min<uint64_t>(n_tiles, t0 + per);
+            // nine band runs; one strided copy when the bands are equally long and the runs whole (every copy costs ~20 us of this thread)
+            const uint64_t wbytes = 26 * (t1 - t0) * nb, o2 = hs + L.band_body_off[0] + 26 * t0 * nb;
+            if (strided && t1 * nb <= L.band_blocks[0] && wbytes % 4u == 0 && o2 % 4u == 0 && er == hipSuccess) {
+                const uint64_t pitch = 26 * L.band_blocks[0];
+                er = hipMemcpy2DAsync(ho + o2, pitch, dob + o2, pitch, wbytes, 9, hipMemcpyDeviceToHost, s2);
+            } else for (int b = 0; b < 9 && er == hipSuccess; ++b) {
+                const uint64_t lo = std::min<uint64_t>(L.band_blocks[b], t0 * nb), hi = std::min<uint64_t>(L.band_blocks[b], t1 * nb);
+                if (hi > lo) er = hipMemcpyAsync(ho + hs + L.band_body_off[b] + 26 * lo, dob + hs + L.band_body_off[b] + 26 * lo, 26 * (hi - lo), hipMemcpyDeviceToHost, s2);
+            }
+            if (c == 0 && er == hipSuccess) {                                          // header and the zero tail of the last word: written by the first chunk's first workgroup
+                er = hipMemcpyAsync(ho, dob, hs, hipMemcpyDeviceToHost, s2);
+                const uint64_t tail = 9 * L.out_words - (hs + L.body_syms);
+                if (er == hipSuccess && tail) er = hipMemcpyAsync(ho + hs + L.body_syms, dob + hs + L.body_syms, tail, hipMemcpyDeviceToHost, s2);
+            }
+            if (er != hipSuccess) { dl_err = er; return; }
+        }
+        dl_err = hipStreamSynchronize(s2);
+    });
+    int rc = T3_OK; uint64_t up_done = 0;
+    for (uint32_t c = 0; c < n_chunks && rc == T3_OK; ++c) {
+        const uint32_t t0 = c * per, t1 = std::min<uint32_t>(n_tiles, t0 + per);
+        const uint64_t S_lo = (uint64_t)t0 * TS, S_hi = (uint64_t)t1 * TS;
+        const uint64_t off_lo = fe == FE_PIXELS ? S_lo / 13 * 18 : S_lo / 26 * 27;   // input bytes in front of the chunk (exact: S_lo is a multiple of the unit)
+        const uint64_t up_hi = t1 == n_tiles ? in_bytes : std::min<uint64_t>(in_bytes, fe == FE_PIXELS ? S_hi / 13 * 18 : S_hi / 26 * 27);
+        if (up_hi > up_done) { const hipError_t er = hipMemcpyAsync((uint8_t*)di + up_done, (const uint8_t*)in + up_done, up_hi - up_done, hipMemcpyHostToDevice, g.stream); if (er != hipSuccess) { rc = fail_hip(er, "hipMemcpyAsync(chunk upload)"); break; } up_done = up_hi; }
+        EncLaunch e = e0;
+        const uint64_t u_lo = off_lo / UB;                                            // pixels / words in front of the chunk
+        e.a.in = (const uint8_t*)di + off_lo;
+        e.a.n_units = n_units > u_lo ? n_units - u_lo : 0; e.a.n_units_pad = (fe_px(fe) ? 2 * n_raw : n_units) - u_lo;
+        e.a.n_sym = (uint32_t)(L.n_sym > S_lo ? L.n_sym - S_lo : 0);
+        e.a.n_tiles = t1 - t0;
+        for (int b = 0; b < 9; ++b) {
+            const uint64_t skip = (uint64_t)t0 * e0.a.band_nb_tile[b];
+            e.a.band_blocks[b] = (uint32_t)(L.band_blocks[b] > skip ? L.band_blocks[b] - skip : 0);
+            e.a.band_body_off[b] = L.band_body_off[b] + 26 * skip;
+            e.a.band_boff6[b] = (uint32_t)((e.a.band_body_off[b] + 4) % 6);
+        }
+        e.a.afrag = lut->d_afrag; e.a.lut_img = lut->d_img;
+        e.a.body_out = (uint8_t*)dout + hs; e.a.frame_out = c == 0 ? (uint8_t*)dout : nullptr;
+        e.a.hdr_syms = hs; e.a.pad_bytes = (uint32_t)(9 * L.out_words - L.out_syms); e.a.out_syms = L.out_syms; memcpy(e.a.hdr, hdr, sizeof hdr);
+        { std::lock_guard<std::mutex> lk(g.mu); rc = launch_enc_fe(fe, e, g.stream); }
+        if (rc == T3_OK) { const hipError_t er = hipEventRecord(evs[c], g.stream); if (er != hipSuccess) rc = fail_hip(er, "hipEventRecord"); }
+        if (rc == T3_OK) launched.store(c + 1, std::memory_order_release);
+    }
+    if (rc != T3_OK) abort_dl.store(1);
+    dl.join();
+    if (rc == T3_OK && dl_err != hipSuccess) rc = fail_hip(dl_err, "chunk download");
+    if (rc == T3_OK) HIPCHK(hipStreamSynchronize(g.stream));
+    return rc;
+}
+
 static int encode_host(int fe, const void* in, uint64_t n_units, const t3_cfg* cfg, void* out, uint64_t cap, uint64_t* n_out) {
     if (!g.ready) return T3_E_NODEVICE;
     if (!cfg || !n_out || (n_units && !in)) return T3_E_ARG;
@@ -713,7 +818,10 @@ static int encode_host(int fe, const void* in, uint64_t n_units, const t3_cfg* c
     *n_out = L.out_words; if (L.out_words > cap) return T3_E_CAPACITY;
     std::lock_guard<std::recursive_mutex> hl(g.host_mu);
     void *di, *dout;
-    { std::lock_guard<std::mutex> lk(g.mu); rc = host_roundtrip_in(0, in, n_units * (fe == FE_PIXELS ? 6 : 9), &di); if (rc) return rc; rc = scratch(1, L.out_words * 9 + 64, &dout); if (rc) return rc; }
+    { std::lock_guard<std::mutex> lk(g.mu); rc = scratch(0, n_units * (fe == FE_PIXELS ? 6 : 9) + 64, &di); if (rc) return rc; rc = scratch(1, L.out_words * 9 + 64, &dout); if (rc) return rc; }
+    rc = encode_host_pipelined(fe, in, n_units, cfg, out, L, di, dout);                 // 1: not this framing / too small -> one upload, one launch, one download
+    if (rc != 1) return rc;
+    if (n_units) HIPCHK(hipMemcpyAsync(di, in, n_units * (fe == FE_PIXELS ? 6 : 9), hipMemcpyHostToDevice, g.stream));
     rc = encode_dev(fe, di, n_units, cfg, dout, L.out_words, n_out, g.stream); if (rc) return rc;
     if (L.out_words) HIPCHK(hipMemcpyAsync(out, dout, L.out_words * 9, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream)); return T3_OK;
@@ -746,4 +854,10 @@ std::mutex& api_qt_mutex() { return g.qt_mu; }
 std::recursive_mutex& api_mail_mutex() { return g.mail_mu; }
 void*& api_slot(int id) { return g.slot[id]; }
 uint32_t* api_ticket_counters(hipStream_t s, int kind) { std::lock_guard<std::mutex> lk(g.mu); return ticket_counters(s, kind); }
+// the download stream and per-chunk events of the pipelined host entry points (the caller holds the context's host mutex)
+int api_pipeline(uint32_t n_events, hipStream_t* s2, hipEvent_t** evs) {
+    if (!g.stream2) HIPCHK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
+    while (g.chunk_ev.size() < n_events) { hipEvent_t ev; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); g.chunk_ev.push_back(ev); }
+    *s2 = g.stream2; *evs = g.chunk_ev.data(); return T3_OK;
+}
 }  // namespace t3

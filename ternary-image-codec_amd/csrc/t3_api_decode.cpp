@@ -9,7 +9,9 @@
 
 #include <algorithm>
 #include <map>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/t3hip.h"
@@ -18,7 +20,7 @@
 
 namespace t3 {
 int api_ready(); hipStream_t api_stream(); int api_scratch(int slot, size_t bytes, void** out, hipStream_t s = nullptr);
-int api_fail_hip(hipError_t e, const char* what); uint32_t* api_flag(); RsTables* api_tables(); int api_n_cu(); int api_device(); std::recursive_mutex& api_host_mutex(); std::mutex& api_tab_mutex(); std::recursive_mutex& api_mail_mutex(); uint32_t* api_ticket_counters(hipStream_t s, int kind);
+int api_fail_hip(hipError_t e, const char* what); uint32_t* api_flag(); RsTables* api_tables(); int api_n_cu(); int api_device(); std::recursive_mutex& api_host_mutex(); std::mutex& api_tab_mutex(); std::recursive_mutex& api_mail_mutex(); uint32_t* api_ticket_counters(hipStream_t s, int kind); int api_pipeline(uint32_t n_events, hipStream_t* s2, hipEvent_t** evs);
 void*& api_slot(int id);          // per-context object slots (t3_api.cpp): this file owns 0..31
 }  // namespace t3
 using namespace t3;
@@ -121,8 +123,11 @@ int rgb_dequant_tables(const uint8_t** out) {
 
 // `body`: the coded stream with `hdr_syms` symbols of header in front of the band-serial body; bcn_period != 0: the body still carries
 // its beacon symbols (slot bcn_slot of every bcn_period-th word, OLD:952-957) and the loads step over them
+// tile_lo / tile_hi (pixels, no beacon): only that range of tiles -- the pipelined host entry decodes a frame chunk by chunk; the kernel
+// sees a frame of its own (band offsets, block counts and the output pointer shifted: tiles are independent).  *tiles_out: the frame's tile count.
 int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_syms, const t3_layout& L, const ScrCycle& sc,
-                       void* d_out, uint64_t units, int to_pixels, uint32_t* d_fail, hipStream_t s, uint32_t bcn_slot = 0, uint32_t bcn_period = 0) {
+                       void* d_out, uint64_t units, int to_pixels, uint32_t* d_fail, hipStream_t s, uint32_t bcn_slot = 0, uint32_t bcn_period = 0,
+                       uint32_t tile_lo = 0, uint32_t tile_hi = 0xFFFFFFFFu, uint32_t* tiles_out = nullptr, uint32_t* units_tile_out = nullptr) {
     if (L.interleave2d || L.n_raw_words == 0) return 1;
     std::lock_guard<std::mutex> lk(g_tab_mu);
     for (int b = 1; b < 9; ++b) if (L.band_k[b] != L.band_k[0]) return 1;
@@ -137,6 +142,18 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
     uint64_t maxb = 0;
     for (int b = 0; b < 9; ++b) { a.band_blocks[b] = (uint32_t)L.band_blocks[b]; a.band_body_off[b] = L.band_body_off[b]; a.band_boff6[b] = (uint32_t)((L.band_body_off[b] + 4) % 6); maxb = std::max<uint64_t>(maxb, L.band_blocks[b]); }
     a.n_tiles = (uint32_t)((maxb + a.nb - 1) / a.nb);
+    if (tiles_out) *tiles_out = a.n_tiles;
+    if (units_tile_out) *units_tile_out = (a.TS / 13u) * 3u;
+    if (tile_lo || tile_hi < a.n_tiles) {
+        if (!to_pixels || bcn_period || tile_lo >= std::min(tile_hi, a.n_tiles)) return T3_E_ARG;
+        const uint64_t u0 = (uint64_t)tile_lo * ((a.TS / 13u) * 3u);
+        for (int b = 0; b < 9; ++b) {
+            const uint64_t skip = (uint64_t)tile_lo * a.nb;
+            a.band_blocks[b] = (uint32_t)(a.band_blocks[b] > skip ? a.band_blocks[b] - skip : 0); a.band_body_off[b] += 26 * skip; a.band_boff6[b] = (uint32_t)((a.band_body_off[b] + 4) % 6);
+        }
+        a.n_tiles = std::min(tile_hi, a.n_tiles) - tile_lo;
+        a.out = (uint8_t*)d_out + u0 * (to_pixels == 2 ? 3u : 6u); a.n_units = units > u0 ? units - u0 : 0;
+    }
     a.cyc24 = sc.cyc24; a.pre0 = sc.pre[0]; a.pre1 = sc.pre[1];
     {   // body symbol i >= 2 sees cyc[(i - 2) mod 6]; a block whose first symbol has phase c0 = (i0 + 4) mod 6 sees cyc[(c0 + p) mod 6] at position p
         uint8_t rows[12][16]; memset(rows, 0, sizeof rows);
@@ -628,6 +645,80 @@ int t3hip_decode_profile_dev(const void* d_in, uint64_t n_in, t3_cfg* seen, void
     return T3_OK;
 }
 
+// Pipelined host decode (round 3; see encode_host_pipelined in t3_api.cpp): FIXED, one k on all bands, 1-D, no beacon, pixels out, a frame
+// of many tiles.  The header is parsed on the host from the caller's buffer; the caller's thread uploads the nine band runs of chunk c
+// and launches the fused decoder on those tiles, a helper thread downloads the pixels of chunk c - 1 meanwhile.  1: not applicable.
+static int decode_host_pipelined(const void* in, uint64_t n_in, t3_cfg* seen, void* out, uint64_t cap, uint64_t* n_out, void* di, void* dout) {
+    if (seen->mode != T3_MODE_FIXED || seen->profile == T3_RAW_MODE || n_in < 10 || getenv("T3HIP_SERIAL_HOST") != nullptr || getenv("T3HIP_GENERIC_DECODE") != nullptr) return 1;
+    t3_cfg cfg = *seen; uint64_t n_raw = 0; uint8_t next[3];
+    if (header_parse((const uint8_t*)in, n_in, T3_MODE_FIXED, cfg, &n_raw, next) != T3_OK) return 1;    // (the serial path reports it)
+    t3_layout L; if (plan(n_raw, cfg, L) != T3_OK || L.out_words > n_in) return 1;
+    if (L.interleave2d || L.beacon_on || 9 * n_in >= (1ull << 32)) return 1;
+    for (int b = 1; b < 9; ++b) if (L.band_k[b] != L.band_k[0]) return 1;
+    const uint64_t units = 2 * n_raw;
+    if (units > cap) return 1;
+    const ScrCycle sc = scrambler_cycle_from_next(next, cfg.seed_s0);
+    const uint32_t hs = L.header_syms, nb = (uint32_t)T3_DEC_PX_NB;
+    uint64_t maxb = 0; for (int b = 0; b < 9; ++b) maxb = std::max<uint64_t>(maxb, L.band_blocks[b]);
+    const uint32_t n_tiles = (uint32_t)((maxb + nb - 1) / nb), units_tile = (9u * nb * (uint32_t)L.band_k[0] / 13u) * 3u;
+    static const uint32_t want_env = getenv("T3HIP_HOST_CHUNKS") ? (uint32_t)atoi(getenv("T3HIP_HOST_CHUNKS")) : 0u;
+    const uint32_t want = want_env ? want_env : 6u;                                  // (FIXED streams start 90 symbols in: the band runs are 2-byte aligned, a strided copy of them is slow -- nine plain copies per chunk, few chunks; t3_api.cpp)
+    if (n_tiles < 64u) return 1;
+    const uint32_t per = (n_tiles + want - 1u) / want, n_chunks = (n_tiles + per - 1u) / per;
+    hipStream_t s = api_stream(), s2 = nullptr; hipEvent_t* evs = nullptr;
+    { const int rc = api_pipeline(n_chunks, &s2, &evs); if (rc) return rc; }
+    *seen = cfg;                                                                       // OLD:1006-1013: the header decoded
+    std::lock_guard<std::recursive_mutex> lk(g_mail_mu);
+    if (!h_flag) { HIPCHK(hipHostMalloc((void**)&h_flag, 64, hipHostMallocMapped)); HIPCHK(hipHostGetDevicePointer((void**)&d_flag_map, h_flag, 0)); }
+    *(volatile uint32_t*)h_flag = 0;
+    std::atomic<uint32_t> launched{0}; std::atomic<int> abort_dl{0};
+    hipError_t dl_err = hipSuccess; const int dev = api_device();
+    uint8_t* const ho = (uint8_t*)out; const uint8_t* const dob = (const uint8_t*)dout;
+    std::thread dl([&] {
+        if (hipSetDevice(dev) != hipSuccess) { dl_err = hipErrorInvalidDevice; return; }
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            while (launched.load(std::memory_order_acquire) <= c) { if (abort_dl.load()) return; std::this_thread::yield(); }
+            hipError_t er = hipEventSynchronize(evs[c]);
+            const uint64_t u0 = std::min<uint64_t>(units, (uint64_t)c * per * units_tile), u1 = std::min<uint64_t>(units, ((uint64_t)c * per + per) * units_tile);
+            if (er == hipSuccess && u1 > u0) er = hipMemcpyAsync(ho + 6 * u0, dob + 6 * u0, 6 * (u1 - u0), hipMemcpyDeviceToHost, s2);
+            if (er != hipSuccess) { dl_err = er; return; }
+        }
+        dl_err = hipStreamSynchronize(s2);
+    });
+    int rc = T3_OK;
+    {   // header words: the device copy of the stream starts with them (the kernel itself never reads them)
+        const hipError_t er = hipMemcpyAsync(di, in, hs, hipMemcpyHostToDevice, s); if (er != hipSuccess) rc = api_fail_hip(er, "hipMemcpyAsync(header)");
+    }
+    for (uint32_t c = 0; c < n_chunks && rc == T3_OK; ++c) {
+        const uint32_t t0 = c * per, t1 = std::min<uint32_t>(n_tiles, t0 + per);
+        bool even = (uint64_t)t1 * nb <= L.band_blocks[0];
+        for (int b = 1; b < 9; ++b) even = even && L.band_blocks[b] == L.band_blocks[0];
+        const uint64_t o2 = hs + L.band_body_off[0] + 26ull * t0 * nb, wbytes = 26ull * (t1 - t0) * nb, pitch = 26 * L.band_blocks[0];
+        if (even && o2 % 4u == 0 && wbytes % 4u == 0 && pitch % 4u == 0 && !getenv("T3HIP_NO_2D_COPY")) {      // nine equally long, 4-byte aligned band runs: one strided copy
+            const hipError_t er = hipMemcpy2DAsync((uint8_t*)di + o2, pitch, (const uint8_t*)in + o2, pitch, wbytes, 9, hipMemcpyHostToDevice, s);
+            if (er != hipSuccess) rc = api_fail_hip(er, "hipMemcpy2DAsync(band runs)");
+        } else for (int b = 0; b < 9 && rc == T3_OK; ++b) {
+            const uint64_t lo = std::min<uint64_t>(L.band_blocks[b], (uint64_t)t0 * nb), hi = std::min<uint64_t>(L.band_blocks[b], (uint64_t)t1 * nb);
+            // (a lane's 16-byte load of a block's second half reaches 0 bytes past the block: runs are exact)
+            if (hi > lo) { const hipError_t er = hipMemcpyAsync((uint8_t*)di + hs + L.band_body_off[b] + 26 * lo, (const uint8_t*)in + hs + L.band_body_off[b] + 26 * lo, 26 * (hi - lo), hipMemcpyHostToDevice, s); if (er != hipSuccess) rc = api_fail_hip(er, "hipMemcpyAsync(band run)"); }
+        }
+        if (rc == T3_OK) {
+            rc = decode_fixed_fused((const uint8_t*)di, 9 * n_in, hs, L, sc, dout, units, 1, d_flag_map, s, 0, 0, t0, t1);
+            if (rc == 1) rc = T3_E_ARG;
+        }
+        if (rc == T3_OK) { const hipError_t er = hipEventRecord(evs[c], s); if (er != hipSuccess) rc = api_fail_hip(er, "hipEventRecord"); }
+        if (rc == T3_OK) launched.store(c + 1, std::memory_order_release);
+    }
+    if (rc != T3_OK) abort_dl.store(1);
+    dl.join();
+    if (rc == T3_OK && dl_err != hipSuccess) rc = api_fail_hip(dl_err, "chunk download");
+    if (rc == T3_OK) { const hipError_t er = hipStreamSynchronize(s); if (er != hipSuccess) rc = api_fail_hip(er, "hipStreamSynchronize"); }
+    if (rc != T3_OK) return rc;
+    *n_out = units;
+    if (*(volatile uint32_t*)h_flag) { *n_out = 0; return T3_E_RS; }                 // OLD:987,1017
+    return T3_OK;
+}
+
 static int decode_host(const void* in, uint64_t n_in, t3_cfg* seen, void* out, uint64_t cap, uint64_t* n_out, int to_pixels) {
     if (!api_ready()) return T3_E_NODEVICE;
     if (!seen || !n_out || (n_in && !in)) return T3_E_ARG;
@@ -636,6 +727,7 @@ static int decode_host(const void* in, uint64_t n_in, t3_cfg* seen, void* out, u
     const uint64_t unit = to_pixels ? 6 : 9, dcap = (to_pixels ? 2 : 1) * (n_in + 16);
     rc = api_scratch(1, dcap * unit + 64, &dout); if (rc) return rc;
     hipStream_t s = api_stream();
+    if (to_pixels == 1) { rc = decode_host_pipelined(in, n_in, seen, out, cap, n_out, di, dout); if (rc != 1) return rc; }   // 1: not that framing -> one upload, the kernels, one download
     if (n_in) HIPCHK(hipMemcpyAsync(di, in, n_in * 9, hipMemcpyHostToDevice, s));
     rc = t3hip_decode_profile_dev(di, n_in, seen, dout, dcap, n_out, to_pixels, s);
     if (rc) return rc;

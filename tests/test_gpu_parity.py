@@ -1028,3 +1028,29 @@ def test_uep_one_launch_decoder(gpu, orc, kw):
             os.environ.pop("T3HIP_TWO_KERNEL_DECODE", None)
         verdicts.append(bool(okp))
     assert verdicts[0] == verdicts[1] == (rc == 0), (kw, verdicts, rc)      # (short codes: the spheres of radius t cover 40 % of the space for r = 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_host_entry_points_pipelined(gpu, orc, mode):
+    """The std::vector-shaped encode entry points on frames of many tiles take the pipelined path (round 3: chunks of whole tiles, upload
+    of chunk c + 1, kernel on chunk c and download of chunk c - 1 overlap; t3_api.cpp encode_host_pipelined): byte-exact against the oracle
+    for pixels and raw words, COMPAT and FIXED, sizes around the chunk and tile edges; the same frame through the serial path
+    (T3HIP_SERIAL_HOST=1) gives the same bytes."""
+    for k_uep, prof in ((2, 2), (0, 0), (3, 3)):
+        cfg, ocfg = both(gpu, dict(profile=prof, uep=k_uep), mode=mode)
+        for n in (1_500_001, 26 * 2284 * 5, 700_000):
+            px = orc.lcg_pixels(n, 4000 + n % 1000)
+            ok, enc = gpu.encode_frame(px, cfg); assert ok
+            rc, want = orc.encode_frame(px, ocfg, cap=n + 64)
+            assert rc == 0 and enc.shape == want.shape and np.array_equal(enc, want), (k_uep, n, "pixels")
+            raw = orc.pack_pixels(px)
+            ok, enc2 = gpu.encode_profile_from_raw(raw, cfg); assert ok
+            assert np.array_equal(enc2, want), (k_uep, n, "words")
+            if n == 700_000:
+                os.environ["T3HIP_SERIAL_HOST"] = "1"
+                try:
+                    ok, enc3 = gpu.encode_frame(px, cfg)
+                finally:
+                    os.environ.pop("T3HIP_SERIAL_HOST", None)
+                assert ok and np.array_equal(enc3, want)
