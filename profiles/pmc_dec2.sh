@@ -16,7 +16,7 @@ for d in sorted(glob.glob('gpurun_out/pmcd2_${tag}_*/')):
     for f in glob.glob(d + '**/*counter_collection.csv', recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            for key in ('decode_fixed', 'decode_stream', 'emit_stream', 'debeacon'):
+            for key in ('decode_fixed', 'decode_uep', 'uep_edge', 'decode_stream', 'emit_stream', 'debeacon'):
                 if key in r['Kernel_Name']: agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
         for key, cs in agg.items():
             for k, v in cs.items(): out.setdefault(key, {})[k] = sum(v) / len(v)
