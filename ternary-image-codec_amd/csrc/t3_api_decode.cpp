@@ -46,6 +46,8 @@ namespace {
 #define d_synd_lut    (&T3_SLOT(uint32_t*, 12)) // [4] per k index: syndrome LUT of the two-kernel decoder
 #define d_roots       (&T3_SLOT(uint32_t*, 16)) // [4] per k index: the Chien search (OLD:611-623) of every locator, tabulated
 #define d_crc_afrag4  T3_SLOT(uint32_t*, 24)    // ... of its FP4 form (t3_crc_fp4.hip)
+#define d_crc_afb     T3_SLOT(uint32_t*, 25)    // FP4 CRC, strided rounds: the feedback slice "append 2048 W zero bytes" ...
+#define crc_afb_w     T3_SLOT(uintptr_t, 26)    // ... and the W it was built for
 #define d_synd_afrag  (&T3_SLOT(uint32_t*, 20)) // [4] per k index: A operand of the syndrome MFMA (t3_host.hpp build_mfma_syndrome)
 uint32_t synd_lut_bytes[4] = {0, 0, 0, 0};      // (a size, the same for every context)
 
@@ -520,7 +522,7 @@ void rgb_shutdown();
 void decode_shutdown() {
     std::lock_guard<std::mutex> lk(g_tab_mu);
     auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
-    fr(d_zpow); fr(d_crc_acc); fr(d_crc_afrag); fr(d_crc_afrag4); fr(d_fxtab); fr(d_fma); fr(d_rgb_dq);
+    fr(d_zpow); fr(d_crc_acc); fr(d_crc_afrag); fr(d_crc_afrag4); fr(d_crc_afb); crc_afb_w = 0; fr(d_fxtab); fr(d_fma); fr(d_rgb_dq);
     if (h_mail) { (void)hipHostFree(h_mail); h_mail = nullptr; }
     if (h_flag) { (void)hipHostFree(h_flag); h_flag = nullptr; d_flag_map = nullptr; }
     rgb_shutdown();
@@ -550,16 +552,20 @@ int decode_init(const RsTables*) {
         }
         HIPCHK(hipMalloc((void**)&d_crc_afrag, af.size() * 4));
         HIPCHK(hipMemcpy(d_crc_afrag, af.data(), af.size() * 4, hipMemcpyHostToDevice));
-        // FP4 form (t3_crc_fp4.hip): 8 data slices (K slot p = 8 d + i of lane half kh in step s carries bit i of byte 32 kh + 4 s + d of the
-        // chunk), the feedback slice and five "append 64 * 2^b bytes" slices (K slot j < 16 of half kh carries the remainder bit in
-        // accumulator row (j & 3) + 8 (j >> 2) + 4 kh; slots 16..31 unused).  A set bit is FP4 1.0 = 0b0010 in nibble p of the lane's 16 bytes.
+        // FP4 form (t3_crc_fp4.hip).  8 data slices: in step s the lane's input dword w (bytes 4 s .. 4 s + 3 of its 32) is fed as the four
+        // dwords w & 0x11111111, w & 0x22222222, w & 0x44444444, (w >> 1) & 0x44444444 -- K slot pos = 8 j + p of lane half kh carries bit
+        // 4 p + j of w, standing at nibble bit j (j < 3: FP4 0.5, 1.0, 2.0) or 2 (j = 3); the slice holds the reciprocal weight, the
+        // product is 1.  The feedback slice and five "append 64 * 2^b bytes" slices: K slot 8 g + q (g, q < 4) of half kh carries the
+        // remainder bit of accumulator e = 4 g + q, row (e & 3) + 8 (e >> 2) + 4 kh, as FP4 0.5 (weight 2.0); the other slots are unused.
+        // FP4 e2m1: 0b0001 = 0.5, 0b0010 = 1.0, 0b0100 = 2.0.
         std::vector<uint32_t> a4((size_t)14 * 64 * 4, 0u);
+        static const uint32_t recip[4] = {4u, 2u, 1u, 1u};                 // weight nibble for a bit at nibble bit 0, 1, 2, 2
         for (int st = 0; st < 14; ++st) for (int kh = 0; kh < 2; ++kh) for (int pos = 0; pos < 32; ++pos) {
-            uint32_t vec;
-            if (st < 8) { const int d = pos >> 3, i = pos & 7, o = 32 * kh + 4 * st + d; vec = adv(tbl[1u << i], 63u - (uint32_t)o); }
-            else if (pos < 16) vec = adv(1u << ((pos & 3) + 8 * (pos >> 2) + 4 * kh), st == 8 ? 2048u : 64u << (st - 9));
+            uint32_t vec, wt;
+            if (st < 8) { const int j = pos >> 3, pn = pos & 7, bit = 4 * pn + j, o = 32 * kh + 4 * st + (bit >> 3); vec = adv(tbl[1u << (bit & 7)], 63u - (uint32_t)o); wt = recip[j]; }
+            else if ((pos & 7) < 4) { const int e = 4 * (pos >> 3) + (pos & 7); vec = adv(1u << ((e & 3) + 8 * (e >> 2) + 4 * kh), st == 8 ? 2048u : 64u << (st - 9)); wt = 4u; }
             else continue;
-            for (int m = 0; m < 32; ++m) if (vec >> m & 1u) a4[((size_t)st * 64 + m + 32 * kh) * 4 + (pos >> 3)] |= 2u << (4 * (pos & 7));
+            for (int m = 0; m < 32; ++m) if (vec >> m & 1u) a4[((size_t)st * 64 + m + 32 * kh) * 4 + (pos >> 3)] |= wt << (4 * (pos & 7));
         }
         HIPCHK(hipMalloc((void**)&d_crc_afrag4, a4.size() * 4));
         HIPCHK(hipMemcpy(d_crc_afrag4, a4.data(), a4.size() * 4, hipMemcpyHostToDevice));
@@ -759,6 +765,8 @@ int t3hip_inject_errors_dev(void* d_words, uint64_t first_sym, uint64_t n_blocks
 
 // the CRC's leading 0xFFFFFFFF carried through n zero bytes (bitwise, 8 n steps would be too slow: square-and-multiply on the operator)
 static uint32_t crc_lead(uint64_t n_bytes) {
+    static thread_local uint64_t last_n = ~0ull; static thread_local uint32_t last_x = 0;   // (a stream of frames of one size asks the same question every frame)
+    if (n_bytes == last_n) return last_x;
     uint32_t x = 0xFFFFFFFFu;
     uint32_t op[32], sq[32];                                          // operator "append 2^j zero bytes" as 32 columns; start with one zero byte
     for (int b = 0; b < 32; ++b) { uint32_t v = 1u << b; for (int i = 0; i < 8; ++i) v = (v & 1u) ? (0xEDB88320u ^ (v >> 1)) : (v >> 1); op[b] = v; }
@@ -768,7 +776,38 @@ static uint32_t crc_lead(uint64_t n_bytes) {
         for (int b = 0; b < 32; ++b) sq[b] = apply(op, op[b]);
         memcpy(op, sq, sizeof op);
     }
+    last_n = n_bytes; last_x = x;
     return x;
+}
+
+// FP4 CRC with strided rounds (t3_crc_fp4.hip): wave g owns rounds g, g + W, ...; a column's running remainder re-enters 2048 W bytes
+// further on.  A slice has the layout of slice 8 of the FP4 slices (decode_init).  Built once per context for W = slots >> l, l = 0 .. kCrcStrideLevels - 1 (shorter streams
+// use fewer waves); the operators by square-and-multiply, crc_lead's way.
+constexpr int kCrcStrideLevels = 8;
+static uint32_t crc_stride_w(uint32_t slots, int l) { return std::max(4u, (slots >> l) & ~3u); }
+static int ensure_crc_feedback(uint32_t slots) {
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    if (d_crc_afb && crc_afb_w == (uintptr_t)slots) return T3_OK;
+    auto apply = [](const uint32_t* m, uint32_t v) { uint32_t r = 0; for (int b = 0; b < 32; ++b) if (v >> b & 1u) r ^= m[b]; return r; };
+    std::vector<uint32_t> a4((size_t)kCrcStrideLevels * 64 * 4, 0u);
+    for (int l = 0; l < kCrcStrideLevels; ++l) {
+        uint32_t op[32], sq[32], acc[32];                             // op = "append 2^j bytes", acc = the operator of the bits of 2048 W seen so far
+        for (int b = 0; b < 32; ++b) { uint32_t v = 1u << b; for (int i = 0; i < 8; ++i) v = (v & 1u) ? (0xEDB88320u ^ (v >> 1)) : (v >> 1); op[b] = v; acc[b] = 1u << b; }
+        for (uint64_t n = 2048ull * crc_stride_w(slots, l); n; n >>= 1) {
+            if (n & 1u) for (int b = 0; b < 32; ++b) acc[b] = apply(op, acc[b]);
+            for (int b = 0; b < 32; ++b) sq[b] = apply(op, op[b]);
+            memcpy(op, sq, sizeof op);
+        }
+        for (int kh = 0; kh < 2; ++kh) for (int e = 0; e < 16; ++e) {     // accumulator e -> dword e >> 2, nibble e & 3, weight 2.0
+            const uint32_t vec = acc[(e & 3) + 8 * (e >> 2) + 4 * kh];
+            for (int m = 0; m < 32; ++m) if (vec >> m & 1u) a4[(((size_t)l * 64) + m + 32 * kh) * 4 + (e >> 2)] |= 4u << (4 * (e & 3));
+        }
+    }
+    if (!d_crc_afb) HIPCHK(hipMalloc((void**)&d_crc_afb, a4.size() * 4));
+    else HIPCHK(hipDeviceSynchronize());                                // (cannot happen: slots is a constant of the context)
+    HIPCHK(hipMemcpy(d_crc_afb, a4.data(), a4.size() * 4, hipMemcpyHostToDevice));
+    crc_afb_w = (uintptr_t)slots;
+    return T3_OK;
 }
 
 // CRC + symbol-sum accumulation of a payload into acc[0] / acc[1] (zeroed here): whole 2 KiB rounds on the matrix cores
@@ -790,8 +829,18 @@ static int launch_crc(const uint8_t* d_data, uint64_t n_bytes, uint32_t* acc, hi
         m.afrag = d_crc_afrag; m.zpow = d_zpow; m.chunk_crc = acc; m.sym_sum = acc + 1;
         const uint64_t waves = ((uint64_t)m.n_rounds + m.rounds_per_wave - 1) / m.rounds_per_wave;
         const bool use_i8 = getenv("T3HIP_CRC_I8") != nullptr;                   // measurement / test knob: the i8 form (t3_crc_mfma.hip)
+        const bool blocked = getenv("T3HIP_CRC_BLOCKED") != nullptr;             // measurement knob: round-2 assignment (consecutive rounds per wave)
         if (use_i8) hipLaunchKernelGGL(crc_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, m);
-        else { m.afrag = d_crc_afrag4; hipLaunchKernelGGL(crc_fp4_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, m); }
+        else if (blocked) { m.afrag = d_crc_afrag4; hipLaunchKernelGGL(crc_fp4_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, m); }
+        else {
+            // strided rounds: W = every wave slot of the chip, halved for shorter streams until a wave has at least 8 rounds
+            { const int rc = ensure_crc_feedback((uint32_t)slots); if (rc) return rc; }
+            int l = 0;
+            while (l + 1 < kCrcStrideLevels && (uint64_t)crc_stride_w((uint32_t)slots, l) * 8 > m.n_rounds) ++l;
+            const uint32_t W = crc_stride_w((uint32_t)slots, l);
+            m.afrag = d_crc_afrag4; m.afb = d_crc_afb + (size_t)l * 64 * 4; m.stride_waves = W;
+            hipLaunchKernelGGL(crc_fp4_kernel, dim3(W / 4), dim3(256), 0, s, m);
+        }
         HIPCHK(hipGetLastError());
         done = (uint64_t)m.n_rounds << 11;
     }

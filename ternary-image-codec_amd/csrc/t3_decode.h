@@ -44,6 +44,8 @@ struct CrcArgs {
 struct CrcMArgs {
     const uint8_t* data; uint64_t n_bytes;       // whole stream (distance to its end)
     uint32_t n_rounds, rounds_per_wave;          // 2 KiB rounds in total / per wave
+    uint32_t stride_waves;                       // FP4 kernel: 0 = a wave owns rounds_per_wave consecutive rounds; W > 0 = wave g owns rounds g, g + W, g + 2 W ..
+    const uint32_t* afb;                         // ... and its feedback slice [64][4] ("append 2048 W zero bytes") comes from here
     const uint32_t* afrag;                       // [22][64][4]: 16 data slices, the feedback slice, five "append 64 * 2^b bytes" slices, in MFMA lane order
     const uint32_t* zpow;
     uint32_t* chunk_crc; uint32_t* sym_sum;

@@ -373,14 +373,16 @@ def test_error_injector_matches_host(gpu, orc):
     assert np.array_equal(d.cpu().numpy(), orc.inject_errors(w, 52, 390, 99, 3))
 
 
-@pytest.mark.parametrize("crc_kernel", ["fp4", "i8"])
+@pytest.mark.parametrize("crc_kernel", ["fp4", "i8", "fp4_blocked"])
 def test_frame_record(gpu, orc, crc_kernel, monkeypatch):
     import torch
     if crc_kernel == "i8":
         monkeypatch.setenv("T3HIP_CRC_I8", "1")          # the i8 form of the matrix-core CRC (the FP4 form is the default)
+    if crc_kernel == "fp4_blocked":
+        monkeypatch.setenv("T3HIP_CRC_BLOCKED", "1")     # consecutive rounds per wave (round 2) instead of strided ones
     rng = np.random.default_rng(4)
     # the last sizes go through the matrix-core rounds; their rests (9 n mod 2048 = 4 .. 2047) are taken by the record kernel itself
-    for n in (0, 1, 6, 255, 256, 257, 100000) + tuple(range(14564, 14564 + 228, 19)) + (14564 + 227, 16384, 20766726 // 64):
+    for n in (0, 1, 6, 255, 256, 257, 100000) + tuple(range(14564, 14564 + 228, 19)) + (14564 + 227, 16384, 20766726 // 64, 1000003, 3000001):   # (the FP4 kernel strides its rounds over 16 .. 2048 waves by size)
         w = rng.integers(0, 27, size=(n, 9), dtype=np.uint8)
         d = torch.from_numpy(w).cuda() if n else torch.zeros(16, dtype=torch.uint8, device="cuda")
         rec = torch.zeros(gpu.FRAME_RECORD_BYTES, dtype=torch.uint8, device="cuda"); scr = torch.zeros(64, dtype=torch.uint8, device="cuda")
