@@ -1183,10 +1183,11 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             if (nxt < a.n_tiles && vw >= w0 && vw - w0 < n_pf) stage_tile(tile_in(nxt * TS), a.stage_off + (par ^ 1u) * a.stage_stride, vw - w0, n_pf);
 #endif
             T3_STAMP(4);
-            uint32_t u_lo = S0;
+            uint32_t u_lo = S0, u_hi = S0 + TS;
 #ifndef T3_ABL_NO_P1
             if constexpr (fe_px(FE)) {
                 const TileIn T = tile_in(S0);
+                u_hi = T.hi[0];
                 P1Run r0 = p1_run<FE>(T.lo[0], T.hi[0], stage + T.off[0]), r1 = p1_run<FE>(T.lo[1], T.hi[1], stage + T.off[1]), r2 = p1_run<FE>(T.lo[2], T.hi[2], stage + T.off[2]);
                 if (T.n < 1u) r0.n_units = 0; if (T.n < 2u) r1.n_units = 0; if (T.n < 3u) r2.n_units = 0;
                 u_lo = T.lo[0];
@@ -1198,7 +1199,36 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             barrier_lds();                                                    // symbols complete
             T3_STAMP(1);
             nn = dyn ? __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + 328)) : nxt + gridDim.x;   // the tile after the next one
-            if constexpr (IL == 1) {
+            if (IL == 1 && (a.il_w & 15u) == 0u) {
+                // Rows of whole 16-byte granules (round 3): the interleave maps every row of the chunk grid onto itself -- even rows stay,
+                // odd rows are mirrored -- and the symbol buffer holds whole rows (tile_in), so the odd rows are reversed IN PLACE: a lane swaps
+                // the 16-byte granules g and G - 1 - g of a row, bytes reversed; phase 2 then reads the tile at its offset inside the
+                // first row.  About a hundred lane tasks per tile; the pass below (every symbol moved into the consumed stage buffer, two
+                // divisions per granule) took 3.5 k of a tile's 12 k cycles (stamp build, profiles/r03/notes.md).
+                const uint32_t G = a.il_w >> 4, G2 = (G + 1u) >> 1, n_rows = (u_hi - u_lo + a.il_w - 1u) / a.il_w;
+                for (uint32_t t = tid; t < n_rows * G2; t += nthr) {
+                    const uint32_t ri = t / G2, g = t - ri * G2, p0 = u_lo + ri * a.il_w;
+                    if (p0 >= a.n_sym) continue;                                    // padding past the stream's end: identity
+                    const uint32_t chunk = fdiv2(p0, a.div_A), base = chunk * a.il_A, r = fdiv2(p0 - base, a.div_w);
+                    if (!(r & 1u)) continue;
+                    const uint32_t take = min(a.il_A, a.n_sym - base), rowlen = min(a.il_w, take - r * a.il_w);
+                    const uint32_t ra = a.sym_off + (p0 - u_lo);                    // 16-byte aligned: rows start at multiples of 16 from u_lo
+                    if (rowlen == a.il_w) {
+                        const uint32_t g1 = G - 1u - g;
+                        const u32x4 x = *T3_LDS_PTR(u32x4, ra + 16u * g), y = *T3_LDS_PTR(u32x4, ra + 16u * g1);
+                        *T3_LDS_WPTR(u32x4, ra + 16u * g) = u32x4{__builtin_bswap32(y.w), __builtin_bswap32(y.z), __builtin_bswap32(y.y), __builtin_bswap32(y.x)};
+                        if (g1 != g) *T3_LDS_WPTR(u32x4, ra + 16u * g1) = u32x4{__builtin_bswap32(x.w), __builtin_bswap32(x.z), __builtin_bswap32(x.y), __builtin_bswap32(x.x)};
+                    } else if (g == 0u) {                                           // the stream's last, short row: one lane, byte by byte
+                        for (uint32_t i = 0; 2u * i + 1u < rowlen; ++i) {
+                            const uint32_t lo = lds_u8(ra + i), hi = lds_u8(ra + rowlen - 1u - i);
+                            *T3_LDS_WPTR(uint8_t, ra + i) = (uint8_t)hi; *T3_LDS_WPTR(uint8_t, ra + rowlen - 1u - i) = (uint8_t)lo;
+                        }
+                    }
+                }
+                barrier_lds();
+                T3_STAMP(3);
+                symb = a.sym_off + (S0 - u_lo);
+            } else if constexpr (IL == 1) {
                 // permutation pass: post-interleave position v of the tile <- pre-interleave symbol il_perm(v) (an involution);
                 // one lane = 4 consecutive positions = one dword of the image phase 2 reads
                 // Rows of the chunk grid map onto themselves, and with rows that are multiples of 4 symbols (tile edges and chunk sizes
