@@ -1,5 +1,5 @@
 """Encode-only loop for profiling (rocprofv3 kernel-trace / PMC passes): N launches of the fused encode entry on one 8K frame.
-argv: [c2|c3|c3u|rgb] [launches] [warmup]   (c3 = BASELINE configs[2]: P5 2-D 64x64 + luma-priority UEP; c3u = 2-D with RS(26,20) on all bands)"""
+argv: [c2|c3|c3u|w1024|w7680|luma1d|rgb] [launches] [warmup]   (c3 = BASELINE configs[2]: P5 2-D 64x64 + luma-priority UEP; c3u = 2-D with RS(26,20) on all bands)"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,7 +12,9 @@ warm = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 t3 = g.load_package(); t3.init(0)
 NPX = 7680 * 4320; P = t3.ProfileID
 cfg = {"c2": t3.make_cfg(profile=P.P3_RS26_20, uep=2), "rgb": t3.make_cfg(profile=P.P3_RS26_20, uep=2),
-       "c3": t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64)), "c3u": t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(64, 64))}[conf]
+       "c3": t3.make_cfg(profile=P.P5_RS26_22_2D, uep="luma", tile=(64, 64)), "c3u": t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(64, 64)),
+       "w1024": t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(1024, 16)), "w7680": t3.make_cfg(profile=P.P5_RS26_22_2D, uep=2, tile=(7680, 8)),
+       "luma1d": t3.make_cfg(profile=P.P3_RS26_20, uep="luma")}[conf]
 s = torch.cuda.current_stream().cuda_stream
 n_enc = t3.encoded_words(NPX // 2, cfg)
 out = torch.zeros(n_enc * 9 + 64, dtype=torch.uint8, device="cuda")

@@ -243,8 +243,10 @@ bool plan_enc_group(const t3_layout& L, const t3_cfg& cfg, uint32_t band_mask, i
             if ((fe_px(fe) || words_packed) && (words_packed ? 2u : 1u) * wpp > std::max(waves, 4u)) continue;
             // UEP kernel: the phases are barrier-separated and a wave runs its sets one after the other, so a tile costs one
             // phase-1 pass plus ceil(sets / 8) set times, whatever the number of busy waves
+            // + a fixed cost per tile (barriers, ticket, prefetch issue, the runs' rounding in 2-D): without it the model preferred tiles of
+            // 5 full waves to larger ones of 7-8 partly filled waves, measured 2-12 % slower (profiles/r03/notes.md: tile sweeps)
             const double cost = grp ? (220.0 + 100.0 * ((sets + 7) / 8)) / (double)(9 * Lq)
-                                    : (180.0 * waves + (fe_px(fe) ? 220.0 * wpp : words_packed ? 250.0 * wpp : 180.0 * waves)) / (double)(9 * Lq);
+                                    : (600.0 + 180.0 * waves + (fe_px(fe) ? 220.0 * wpp : words_packed ? 250.0 * wpp : 180.0 * waves)) / (double)(9 * Lq);
             const double score = 1.0 / cost + 1e-9 * (double)Lq;
             if (score > best_score) { best_score = score; best_q = q; }
         }

@@ -350,29 +350,30 @@ __device__ __forceinline__ void il_row(uint32_t u, const EncArgs& a, uint32_t& r
 // segment, so whole rows of the tile come from themselves and only the tile's partial first / last row comes from the mirrored
 // piece of that row -- at most three runs of consecutive pre-interleave positions (ascending, adjacent ones merged), TS symbols
 // in all, whatever the row width.  Positions past the end of the stream map to themselves.
-struct IlRuns { uint32_t lo[3], hi[3], n; };
+struct IlRuns { uint32_t lo[3], hi[3], plo[3], n; };      // plo: post-interleave position of the run's lowest-placed symbol (its symbols occupy [plo, plo + hi - lo) of the tile)
 __device__ __forceinline__ IlRuns il_runs(uint32_t S0, uint32_t TS, const EncArgs& a) {
-    IlRuns R; R.n = 0; R.lo[0] = R.lo[1] = R.lo[2] = 0; R.hi[0] = R.hi[1] = R.hi[2] = 0;
-    auto push = [&](uint32_t lo, uint32_t hi) {                                // (no dynamic indexing: the runs stay in registers)
+    IlRuns R; R.n = 0; R.lo[0] = R.lo[1] = R.lo[2] = 0; R.hi[0] = R.hi[1] = R.hi[2] = 0; R.plo[0] = R.plo[1] = R.plo[2] = 0;
+    auto push = [&](uint32_t lo, uint32_t hi, uint32_t plo) {                  // (no dynamic indexing: the runs stay in registers)
         if (lo >= hi) return;
-        if (R.n == 0u) { R.lo[0] = lo; R.hi[0] = hi; R.n = 1u; }
-        else if (R.n == 1u) { if (R.hi[0] == lo) R.hi[0] = hi; else { R.lo[1] = lo; R.hi[1] = hi; R.n = 2u; } }
-        else if (R.n == 2u) { if (R.hi[1] == lo) R.hi[1] = hi; else { R.lo[2] = lo; R.hi[2] = hi; R.n = 3u; } }
+        // adjacent runs are merged when their places are adjacent too (identity-placed neighbours; a mirrored piece never is)
+        if (R.n == 0u) { R.lo[0] = lo; R.hi[0] = hi; R.plo[0] = plo; R.n = 1u; }
+        else if (R.n == 1u) { if (R.hi[0] == lo && R.plo[0] + (R.hi[0] - R.lo[0]) == plo) R.hi[0] = hi; else { R.lo[1] = lo; R.hi[1] = hi; R.plo[1] = plo; R.n = 2u; } }
+        else if (R.n == 2u) { if (R.hi[1] == lo && R.plo[1] + (R.hi[1] - R.lo[1]) == plo) R.hi[1] = hi; else { R.lo[2] = lo; R.hi[2] = hi; R.plo[2] = plo; R.n = 3u; } }
         else if (R.hi[2] == lo) R.hi[2] = hi;
     };
     const uint32_t E = min(S0 + TS, a.n_sym);
     if (S0 < E) {
         uint32_t rl0, rn0, od0, rl1, rn1, od1;
         il_row(S0, a, rl0, rn0, od0); il_row(E - 1u, a, rl1, rn1, od1);
-        if (rl0 == rl1) push(od0 ? rl0 + rn0 - (E - rl0) : S0, od0 ? rl0 + rn0 - (S0 - rl0) : E);
+        if (rl0 == rl1) push(od0 ? rl0 + rn0 - (E - rl0) : S0, od0 ? rl0 + rn0 - (S0 - rl0) : E, S0);
         else {
             const uint32_t he = rl0 + rn0;
-            push(od0 ? rl0 : S0, od0 ? he - (S0 - rl0) : he);
-            push(he, rl1);
-            push(od1 ? rl1 + rn1 - (E - rl1) : rl1, od1 ? rl1 + rn1 : E);
+            push(od0 ? rl0 : S0, od0 ? he - (S0 - rl0) : he, S0);
+            push(he, rl1, he);
+            push(od1 ? rl1 + rn1 - (E - rl1) : rl1, od1 ? rl1 + rn1 : E, rl1);
         }
     }
-    push(max(S0, a.n_sym), S0 + TS);
+    push(max(S0, a.n_sym), S0 + TS, max(S0, a.n_sym));
     return R;
 }
 
@@ -738,22 +739,26 @@ __device__ __forceinline__ void rgb_px_to_comps(const uint32_t r8, const uint32_
 
 // One run of consecutive pixel triples for phase 1: triples [t_base, t_end) in lane units of four (t_base a multiple of 4); triple t
 // reads its input at LDS address src0 + t * (18 | 9) (pixels | RGB)
-struct P1Run { uint32_t t_base, t_end, n_units, src0; };
+struct P1Run { uint32_t t_base, t_end, n_units, src0, lo, hi, dst0; };   // lo, hi, dst0: run-placed 2-D flow (symbol u of [lo, hi) goes to LDS address dst0 + u)
 template <int FE>
 __device__ __forceinline__ P1Run p1_run(uint32_t u_lo, uint32_t u_hi, uint32_t stage) {    // symbols [u_lo, u_hi), their input staged at `stage` (see stage_input)
     constexpr uint32_t GBf = FE == FE_PIXELS ? kGroupBytes : kGroupBytesRgb, TB = FE == FE_PIXELS ? 18u : 9u;
     P1Run r; r.t_base = (u_lo / 13u) & ~3u; r.t_end = (u_hi + 12u) / 13u; r.n_units = (r.t_end - r.t_base + 3u) / 4u;
     const uint64_t b0 = ((uint64_t)(r.t_base / 2u) * GBf) & ~15ull;                       // 16-aligned start of the first lane group (two triples each)
     r.src0 = stage - (uint32_t)b0;                                                       // (wraps; src0 + t * TB does not)
+    r.lo = u_lo; r.hi = u_hi; r.dst0 = 0;
     (void)TB;
     return r;
 }
 
 // IL: the symbols go to their post-interleave places in the tile [S0, S0 + TS) (what falls outside belongs to another tile);
 // else symbol u goes to sym_off + (u - S0).
+// placed (IL only, wave-uniform): the run-placed flow -- a run's symbols go, in pre-interleave order, to the place the run occupies in the
+// tile (P1Run::dst0; rows, chunks and tile edges are multiples of 4 there, so aligned dwords stay aligned dwords) and the caller
+// reverses the odd rows' pieces in place afterwards.
 template <int SC, int FE, bool IL>
 __device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, const P1Run r0, const P1Run r1, const P1Run r2, uint32_t S0, uint32_t TS,
-                                                      uint32_t lane, uint32_t wave, uint32_t nwv) {
+                                                      uint32_t lane, uint32_t wave, uint32_t nwv, const bool placed = false) {
     constexpr uint32_t TB = FE == FE_PIXELS ? 18u : 9u;
     const uint32_t nw1 = min(a.p1_wpp, nwv);                                      // waves that convert (planner: just enough lanes)
     if (wave >= nw1) return;
@@ -846,6 +851,21 @@ __device__ __forceinline__ void convert_pixels_packed(const EncArgs& a, const P1
 #pragma unroll
                 for (uint32_t j = 0; j < 6; ++j) *T3_LDS_WPTR(u32x2a4, dst + 8u * j) = u32x2a4{o[2 * j], o[2 * j + 1]};
                 *T3_LDS_WPTR(uint32_t, dst + 48u) = o[12];
+            }
+        } else if (placed) {
+            const uint32_t lo = ri == 0u ? r0.lo : ri == 1u ? r1.lo : r2.lo, hi = ri == 0u ? r0.hi : ri == 1u ? r1.hi : r2.hi;
+            const uint32_t u0 = 13u * t, dst = (ri == 0u ? r0.dst0 : ri == 1u ? r1.dst0 : r2.dst0) + u0;     // dword aligned
+            const bool inside = live && u0 >= lo && u0 + 52u <= hi;
+            if (inside) {
+#pragma unroll
+                for (uint32_t j = 0; j < 6; ++j) *T3_LDS_WPTR(u32x2a4, dst + 8u * j) = u32x2a4{o[2 * j], o[2 * j + 1]};
+                *T3_LDS_WPTR(uint32_t, dst + 48u) = o[12];
+            }
+            if (__builtin_amdgcn_ballot_w64(live && !inside) != 0) {              // the few lane units a run's ends cut through: dword by dword
+                if (live && !inside) {
+#pragma unroll
+                    for (uint32_t j = 0; j < 13; ++j) { const uint32_t u = u0 + 4u * j; if (u >= lo && u < hi) *T3_LDS_WPTR(uint32_t, dst + 4u * j) = o[j]; }
+                }
             }
         } else if (live) {
             // 2-D boustrophedon folded into the stores (OLD:750-780): with rows, chunks and the tile start multiples of 4 an aligned
@@ -1115,9 +1135,9 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
     constexpr bool fast = !IL || fe_px(FE);                                    // (the host sets a.il_async == IL for pixel / RGB input, 0 for raw words)
     // the runs of a tile and where each one's input sits in a stage buffer: run i at kRunPitch-rounded offsets (an LDS-DMA piece is
     // a whole KiB, so a run's last piece may reach up to 1008 bytes past its end)
-    struct TileIn { uint32_t lo[3], hi[3], off[3], n; };
+    struct TileIn { uint32_t lo[3], hi[3], off[3], plo[3], n; };
     auto tile_in = [&](uint32_t S) -> TileIn {
-        TileIn T; T.n = 1; T.lo[0] = S; T.hi[0] = S + TS; T.off[0] = 0; T.lo[1] = T.lo[2] = T.hi[1] = T.hi[2] = 0; T.off[1] = T.off[2] = 0;
+        TileIn T; T.n = 1; T.lo[0] = S; T.hi[0] = S + TS; T.off[0] = 0; T.lo[1] = T.lo[2] = T.hi[1] = T.hi[2] = 0; T.off[1] = T.off[2] = 0; T.plo[0] = S; T.plo[1] = T.plo[2] = 0;
         if constexpr (IL == 1 && fe_px(FE)) {                                  // narrow rows: the whole row segments the tile overlaps, one run
             if (S < a.n_sym) { T.lo[0] = il_row_start(S, a); T.hi[0] = max(il_row_end(min(S + TS, a.n_sym) - 1u, a), S + TS); }
             return T;
@@ -1127,7 +1147,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             T.n = R.n; uint32_t off = 0;
 #pragma unroll
             for (uint32_t i = 0; i < 3; ++i) {
-                T.lo[i] = R.lo[i]; T.hi[i] = R.hi[i]; T.off[i] = off;
+                T.lo[i] = R.lo[i]; T.hi[i] = R.hi[i]; T.off[i] = off; T.plo[i] = R.plo[i];
                 const uint32_t bytes = (uint32_t)((uint64_t)end_group(R.hi[i]) * GBf - (((uint64_t)first_group(R.lo[i]) * GBf) & ~15ull));
                 if (i < R.n) off += (bytes + 1023u + 16u) & ~1023u;
             }
@@ -1184,6 +1204,7 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
 #endif
             T3_STAMP(4);
             uint32_t u_lo = S0, u_hi = S0 + TS;
+            bool placed = false;                                              // IL == 2: this tile goes through the run-placed flow
 #ifndef T3_ABL_NO_P1
             if constexpr (fe_px(FE)) {
                 const TileIn T = tile_in(S0);
@@ -1191,14 +1212,48 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
                 P1Run r0 = p1_run<FE>(T.lo[0], T.hi[0], stage + T.off[0]), r1 = p1_run<FE>(T.lo[1], T.hi[1], stage + T.off[1]), r2 = p1_run<FE>(T.lo[2], T.hi[2], stage + T.off[2]);
                 if (T.n < 1u) r0.n_units = 0; if (T.n < 2u) r1.n_units = 0; if (T.n < 3u) r2.n_units = 0;
                 u_lo = T.lo[0];
+                if constexpr (IL == 2) {
+                    // run-placed flow (round 3): whole rows of multiples of 4 symbols, the tile inside the stream; the stream's last tiles
+                    // (ragged last row, padding) and other geometries keep the cursor flow
+                    placed = (a.il_w & 3u) == 0u && ((a.il_A & 3u) == 0u || a.il_A >= a.n_sym) && (S0 & 3u) == 0u && (TS & 3u) == 0u && S0 + TS <= a.n_sym
+                             && il_row_end(S0 + TS - 1u, a) - il_row_start(S0 + TS - 1u, a) == a.il_w;
+                    r0.dst0 = a.sym_off + (T.plo[0] - S0) - T.lo[0]; r1.dst0 = a.sym_off + (T.plo[1] - S0) - T.lo[1]; r2.dst0 = a.sym_off + (T.plo[2] - S0) - T.lo[2];   // (wraps; dst0 + u does not)
+                }
                 if constexpr (IL == 1) convert_pixels_packed<(1 << SH), FE, false>(a, r0, r1, r2, u_lo, TS, lane, vw, nwv);   // pre-interleave order; the pass below moves them
-                else convert_pixels_packed<(1 << SH), FE, IL == 2>(a, r0, r1, r2, S0, TS, lane, vw, nwv);
+                else convert_pixels_packed<(1 << SH), FE, IL == 2>(a, r0, r1, r2, S0, TS, lane, vw, nwv, placed);
             } else convert_words_packed<SH>(a, w1_run(S0, S0 + TS, stage), S0, lane, vw, nwv);
 #endif
             T3_STAMP(5);                                                      // (diagnostic) this wave's conversion
             barrier_lds();                                                    // symbols complete
             T3_STAMP(1);
             nn = dyn ? __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + 328)) : nxt + gridDim.x;   // the tile after the next one
+            if (IL == 2 && placed) {
+                // the odd rows' pieces inside the tile, reversed in place (dword pairs, bytes swapped): the tile's first row from S0, whole
+                // rows, the last row up to the tile's end -- one lane = the dwords i and n - 1 - i of a piece
+                const uint32_t E = S0 + TS;
+                uint32_t rl0, rn0, od0; il_row(S0, a, rl0, rn0, od0);
+                const uint32_t he = min(rl0 + rn0, E);                            // end of the first row's piece
+                const uint32_t w8 = (a.il_w + 7u) >> 3;                           // lane tasks of a whole row
+                const uint32_t n0 = od0 ? (he - S0 + 7u) >> 3 : 0u;
+                const uint32_t rows = (E - he + a.il_w - 1u) / a.il_w;            // further rows the tile touches (the last one maybe in part)
+                for (uint32_t t = tid; t < n0 + rows * w8; t += nthr) {
+                    uint32_t pa, len, i;                                          // piece start (post position), length, dword index
+                    if (t < n0) { pa = S0; len = he - S0; i = t; }
+                    else {
+                        const uint32_t ri = (t - n0) / w8; i = (t - n0) - ri * w8;
+                        pa = he + ri * a.il_w; len = min(a.il_w, E - pa);
+                        const uint32_t chunk = fdiv2(pa, a.div_A), r = fdiv2(pa - chunk * a.il_A, a.div_w);
+                        if (!(r & 1u)) continue;
+                    }
+                    const uint32_t nd = len >> 2, j = nd - 1u - i;
+                    if (i > j || i >= nd) continue;
+                    const uint32_t ad = a.sym_off + (pa - S0);
+                    const uint32_t x = lds_u32(ad + 4u * i), y = lds_u32(ad + 4u * j);
+                    *T3_LDS_WPTR(uint32_t, ad + 4u * i) = __builtin_bswap32(y);
+                    if (i != j) *T3_LDS_WPTR(uint32_t, ad + 4u * j) = __builtin_bswap32(x);
+                }
+                barrier_lds();
+            }
             if (IL == 1 && (a.il_w & 15u) == 0u) {
                 // Rows of whole 16-byte granules (round 3): the interleave maps every row of the chunk grid onto itself -- even rows stay,
                 // odd rows are mirrored -- and the symbol buffer holds whole rows (tile_in), so the odd rows are reversed IN PLACE: a lane swaps
