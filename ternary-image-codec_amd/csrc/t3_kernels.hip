@@ -423,7 +423,7 @@ constexpr uint32_t kMfmaModOff = 3 * 4096, kMfmaScr = 336;     // must match t3_
 // index -> band bytes (UEP groups) or ~0 for the identity (one k on all nine bands).
 struct P2Map { uint32_t item0[2]; uint32_t n_items, nb; DevDiv div_nb; uint32_t band_tab, scr_off; };
 
-template <int R, bool GRP, bool BCN>      // BCN: beacon insertion fused into the stores; GRP: UEP group call (one set, band table, the group's scrambler dwords); else one k on all nine bands (two sets)
+template <int R, bool GRP, bool BCN, bool REGEO = false>      // BCN: beacon insertion fused into the stores; GRP: UEP group call (one set, band table, the group's scrambler dwords); else one k on all nine bands (two sets); REGEO: see load()
 __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t symb, uint32_t tile, uint32_t lane, const v4i (&Afr)[3], const P2Map& M) {
     constexpr uint32_t K = 26 - R, H = R / 2;
     constexpr uint32_t TB = GRP ? kLdsHdrUep : kLdsHdr, MB = TB + kMfmaModOff;
@@ -433,7 +433,10 @@ __device__ __forceinline__ uint32_t phase2_mfma(const EncArgs& a, uint32_t symb,
     // second set's two dependent LDS round trips hide under the first set's chain and epilogue.
     struct Set { v4i Bv[3]; uint32_t W[3]; uint32_t c0, mg; uint64_t goff; bool valid, first; uint32_t dd0, dd1; };
     auto load = [&](uint32_t set, Set& s) {
-        const uint32_t item = M.item0[set] + n;                               // blocks are dealt linearly across the bands (item0 huge: no set)
+        uint32_t nn = n;
+        if constexpr (REGEO) asm volatile("" : "+v"(nn));                     // the wave's items never change: hoisted out of the tile loop, both sets' block geometry was kept in (spilled)
+                                                                              // registers by the kernels that are over the 80-VGPR budget (reloads + vmcnt(0) in every tile): those recompute it
+        const uint32_t item = M.item0[set] + nn;                              // blocks are dealt linearly across the bands (item0 huge: no set)
         const uint32_t bi = min(fdiv(item, M.div_nb), 8u), m = item - bi * M.nb;
         uint32_t b = bi;
         if constexpr (GRP) b = lds_u8(M.band_tab + bi);
@@ -1374,7 +1377,14 @@ __device__ __forceinline__ void encode_body(const EncArgs& a) {
             if constexpr (RSEL > 1) {                                          // one k on all nine bands: both sets of the wave in one call
                 P2Map M; M.item0[0] = wave * 64u; M.item0[1] = wave * 64u + 32u; M.n_items = a.n_items; M.nb = a.nb_uniform; M.div_nb = a.div_nb;
                 M.band_tab = ~0u; M.scr_off = kMfmaScr;
-                younger = phase2_mfma<RSEL, false, BCN>(a, symb, tile, lane, Afr, M);
+                // REGEO (recompute the block geometry per tile instead of keeping it across the tile loop): chosen per instantiation from the
+                // register allocator's result (profiles/kernel_resources.py: spilled VGPRs with / without) -- RS(26,20) from pixels / raw words
+                // fits the 80-VGPR budget as it is, most others stop spilling with it, a few spill less without it
+                constexpr bool regeo = FE == FE_RGB ? (RSEL != 6 || IL == 2) : RSEL == 6 ? false
+                    : (FE == FE_PIXELS && IL == 0 && RSEL == 8 && !BCN) ? false
+                    : (FE == FE_PIXELS && IL == 2 && (RSEL == 2 || (RSEL == 4 && BCN))) ? false
+                    : (FE == FE_WORDS && IL == 1 && (RSEL == 2 || RSEL == 8)) ? false : true;
+                younger = phase2_mfma<RSEL, false, BCN, regeo>(a, symb, tile, lane, Afr, M);
             } else if constexpr (RSEL == 1) {                                  // UEP: a set lies inside one group of bands that share k
                 younger = 0;
 #pragma unroll

@@ -262,8 +262,8 @@ def test_host_block_codec_matches_oracle(built):
 
 def test_no_vgpr_spills_in_hot_kernels(built):
     """Register budget of the gfx950 code objects, read from the built objects' notes (hipcc cross-compiles without a GPU):
-    the kernels of the bench step and of the RGB / raw-word / pixel entry points at the headline code RS(26,20) carry NO spilled
-    VGPR, and no kernel of the 1-D RGB front end reloads a spilled register inside its persistent tile loop (a scratch reload is
+    the kernels of the bench step and every 1-D fused encoder (any input, any code) carry NO spilled VGPR, and none of them reloads a
+    spilled register inside its persistent tile loop (a scratch reload is
     followed by s_waitcnt vmcnt(0), which drains the next tile's prefetch in the middle of a phase: profiles/r02/notes.md).
     Every instantiation's figures: `python3 profiles/kernel_resources.py`."""
     import sys
@@ -271,10 +271,12 @@ def test_no_vgpr_spills_in_hot_kernels(built):
     import kernel_resources as kr
     ks = kr.all_kernels()
     assert len(ks) > 100
-    must_be_clean = ["encode_kernel_k<0, 0, 6, false>", "encode_kernel_k<0, 0, 6, true>", "encode_kernel_k<1, 0, 6, false>", "encode_kernel_k<1, 0, 6, true>",
-                     "encode_kernel_k<2, 0, 6, false>", "encode_kernel_k<2, 0, 6, true>", "encode_kernel_k<2, 0, 2, false>", "encode_kernel_k<2, 0, 8, false>",
-                     "encode_kernel_uep<0, 0, false>", "encode_kernel_uep<2, 0, false>", "encode_kernel_uep<0, 1, false>", "encode_kernel_uep<2, 1, false>",
-                     "decode_fixed_px_kernel<6, false, false>", "decode_fixed_px_kernel<6, true, false>", "crc_fp4_kernel", "crc_mfma_kernel"]
+    # every 1-D fused encoder (pixels / raw words / RGB in, the four codes, with and without the fused beacon), the 2-D ones of the headline
+    # code without beacon, the UEP kernels, the bench step's decoder and CRC kernels
+    must_be_clean = ["encode_kernel_k<%d, 0, %d, %s>" % (fe, r, b) for fe in (0, 1, 2) for r in (2, 4, 6, 8) for b in ("false", "true")]
+    must_be_clean += ["encode_kernel_k<%d, %d, 6, false>" % (fe, il) for fe in (0, 2) for il in (1, 2)] + ["encode_kernel_k<1, 1, 6, false>"]
+    must_be_clean += ["encode_kernel_uep<0, 0, false>", "encode_kernel_uep<2, 0, false>", "encode_kernel_uep<0, 1, false>", "encode_kernel_uep<2, 1, false>",
+                      "decode_fixed_px_kernel<6, false, false>", "decode_fixed_px_kernel<6, true, false>", "crc_fp4_kernel", "crc_mfma_kernel"]
     for want in must_be_clean:
         hit = [n for n in ks if want in n]
         assert hit, want
@@ -284,5 +286,5 @@ def test_no_vgpr_spills_in_hot_kernels(built):
     loops = kr.loop_scratch()
     assert len(loops) > 60
     for n, (ld, st) in loops.items():
-        if any(w in n for w in must_be_clean) or "encode_kernel_k<2, 0, 2" in n or "encode_kernel_k<2, 0, 8, false" in n:
+        if any(w in n for w in must_be_clean):
             assert (ld, st) == (0, 0), (n, ld, st)
