@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--encode-only", action="store_true", help="profiling aid: skip decode + index in the loop")
     ap.add_argument("--overlap-record", action="store_true", help="index record on a second HIP stream beside the decode (round 1's default; the round-2 decoder leaves the CRC kernel no registers to run beside it, so the record now follows on the main stream)")
     ap.add_argument("--serial", action="store_true", help="(default now) index record on the main stream")
+    ap.add_argument("--record-last", action="store_true", help="index record behind the decode (rounds 1-2) instead of right behind the encode whose output it reads")
     ap.add_argument("--sync-decode", action="store_true", help="every frame through the synchronous decode entry (host-parsed header, two synchronisations per frame)")
     ap.add_argument("--no-verify", action="store_true", help="profiling aid for timing-only ablation builds (results are wrong by construction)")
     args = ap.parse_args()
@@ -268,7 +269,8 @@ def main():
     d_enc = torch.zeros(n_enc * 9 + 64, dtype=torch.uint8, device=dev)
     d_back = torch.zeros(NPX * 6 + 64, dtype=torch.uint8, device=dev)
     d_recs = torch.zeros((max(args.steps, 1), t3.FRAME_RECORD_BYTES), dtype=torch.uint8, device=dev)
-    d_scr = torch.zeros(64, dtype=torch.uint8, device=dev)
+    scr_bytes = t3.frame_record_scratch_bytes(n_enc)
+    d_scr = torch.zeros(scr_bytes, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     # the stream's first frame: synchronous entry, header parsed on the host -> the configuration the following frames are decoded with
     dctx = t3.DecoderContext(mode=t3.MODE_FIXED)
@@ -288,10 +290,14 @@ def main():
             ev[1].record(stream)
         if args.encode_only:
             return
-        rec_args = (d_enc.data_ptr(), n_enc, i * world + rank, cfg, d_recs[i % len(d_recs)].data_ptr(), d_scr.data_ptr(), 64)
+        rec_args = (d_enc.data_ptr(), n_enc, i * world + rank, cfg, d_recs[i % len(d_recs)].data_ptr(), d_scr.data_ptr(), scr_bytes)
         if s2 is not None:
             enc_done.record(cur); s2.wait_event(enc_done)
             t3.frame_record_dev(*rec_args, s2.cuda_stream); rec_done.record(s2)
+        if s2 is None and not args.record_last:
+            t3.frame_record_dev(*rec_args, stream)          # the record reads what the encoder has just written (still in the memory-side cache)
+        if ev is not None:
+            ev[3].record(stream)                            # the decoder's interval starts here
         if args.sync_decode:
             seen = t3.DecoderContext(mode=t3.MODE_FIXED).cfg_last_seen
             rc, n = t3.decode_profile_dev(d_fenc[j].data_ptr(), n_fenc, seen, d_back.data_ptr(), NPX, True, stream)
@@ -301,7 +307,7 @@ def main():
             assert n == NPX
         if ev is not None:
             ev[2].record(stream)
-        if s2 is None:
+        if s2 is None and args.record_last:
             t3.frame_record_dev(*rec_args, stream)
 
     def exchange():
@@ -328,7 +334,7 @@ def main():
     if multi and not args.encode_only:                     # untimed: RCCL builds its channels on the first collective of a communicator
         exchange(); torch.cuda.synchronize(); dist.barrier()
     torch.cuda.synchronize()
-    events = [[t3.Event(), t3.Event(), t3.Event()] for _ in range(args.steps)]
+    events = [[t3.Event(), t3.Event(), t3.Event(), t3.Event()] for _ in range(args.steps)]
     gathered = None
 
     if multi:
@@ -386,7 +392,7 @@ def main():
             dist.destroy_process_group()
         return
     enc_ms = [events[i][0].elapsed_ms(events[i][1]) for i in range(args.steps)]
-    dec_ms = [events[i][1].elapsed_ms(events[i][2]) for i in range(args.steps)] if not args.encode_only else [float("nan")]
+    dec_ms = [events[i][3].elapsed_ms(events[i][2]) for i in range(args.steps)] if not args.encode_only else [float("nan")]
     enc_avg = sum(enc_ms) / len(enc_ms); dec_avg = sum(dec_ms) / len(dec_ms)
     alg_bytes = 6 * NPX + 9 * n_enc                       # read 6 B/px, write 9 B/word = 385,966,134 B
     achieved = alg_bytes / (enc_avg * 1e-3) / 1e9

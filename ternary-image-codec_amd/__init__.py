@@ -536,6 +536,11 @@ def inject_errors_dev(d_words, first_sym, n_blocks, seed, max_err, stream=0):
     _chk(lib().t3hip_inject_errors_dev(C.c_void_p(d_words), C.c_uint64(first_sym), C.c_uint64(n_blocks), C.c_uint32(seed), C.c_int(max_err), C.c_void_p(stream)), "t3hip_inject_errors_dev")
 
 
+def frame_record_scratch_bytes(n_words=0):
+    """Scratch t3hip_frame_record_dev wants (64 bytes still work: two accumulators, a fill kernel and atomics instead of per-workgroup partials)."""
+    return int(lib().t3hip_frame_record_scratch_bytes(C.c_uint64(n_words)))
+
+
 def frame_record_dev(d_words, n_words, frame_idx, cfg, d_rec, d_scratch, scratch_bytes=64, stream=0):
     _chk(lib().t3hip_frame_record_dev(C.c_void_p(d_words), C.c_uint64(n_words), C.c_uint64(frame_idx), C.byref(cfg), C.c_void_p(d_rec), C.c_void_p(d_scratch), C.c_uint64(scratch_bytes), C.c_void_p(stream)), "t3hip_frame_record_dev")
 

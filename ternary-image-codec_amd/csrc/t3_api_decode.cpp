@@ -813,8 +813,16 @@ static int ensure_crc_feedback(uint32_t slots) {
 // CRC + symbol-sum accumulation of a payload into acc[0] / acc[1] (zeroed here): whole 2 KiB rounds on the matrix cores
 // when the buffer is 16-byte aligned, the rest (or everything) through the table kernel
 // tail_off != null: a rest shorter than 2 KiB behind the matrix-core rounds is left to the caller's record kernel (*tail_off = where it starts)
-static int launch_crc(const uint8_t* d_data, uint64_t n_bytes, uint32_t* acc, hipStream_t s, uint64_t* tail_off = nullptr) {
-    HIPCHK(hipMemsetAsync(acc, 0, 8, s));
+// partials / cap_wg / n_partials (frame record): when the strided FP4 kernel takes the whole stream but its rest and its grid fits cap_wg, the
+// workgroups store their contributions side by side in `partials` (*n_partials = how many) and the accumulators are left alone: no
+// 8-byte fill kernel in front (4.5 us of stream time) and no atomics; the record kernel folds them.
+constexpr uint32_t kRecordPartialWgs = 1024;
+static int launch_crc(const uint8_t* d_data, uint64_t n_bytes, uint32_t* acc, hipStream_t s, uint64_t* tail_off = nullptr, uint32_t* partials = nullptr, uint32_t cap_wg = 0, uint32_t* n_partials = nullptr) {
+    const bool fp4_whole = ((uintptr_t)d_data & 15u) == 0 && n_bytes >= 64 * 2048 && (n_bytes >> 11) < (1ull << 32) && n_bytes < (1ull << kCrcPows) && getenv("T3HIP_CRC_TABLES") == nullptr &&
+                           getenv("T3HIP_CRC_I8") == nullptr && getenv("T3HIP_CRC_BLOCKED") == nullptr && tail_off != nullptr;
+    const bool use_partials = partials && n_partials && fp4_whole && getenv("T3HIP_CRC_ATOMICS") == nullptr;   // (T3HIP_CRC_ATOMICS: measurement / test knob)
+    if (n_partials) *n_partials = 0;
+    if (!use_partials) HIPCHK(hipMemsetAsync(acc, 0, 8, s));
     uint64_t done = 0;
     static const int rpw_env = [] { const char* e = getenv("T3HIP_CRC_ROUNDS_PER_WAVE"); return e ? atoi(e) : 0; }();
     if (((uintptr_t)d_data & 15u) == 0 && n_bytes >= 64 * 2048 && (n_bytes >> 11) < (1ull << 32) && n_bytes < (1ull << kCrcPows) && getenv("T3HIP_CRC_TABLES") == nullptr) {   // (the epilogue walks the distance bit by bit over kCrcPows operators)
@@ -839,6 +847,8 @@ static int launch_crc(const uint8_t* d_data, uint64_t n_bytes, uint32_t* acc, hi
             while (l + 1 < kCrcStrideLevels && (uint64_t)crc_stride_w((uint32_t)slots, l) * 8 > m.n_rounds) ++l;
             const uint32_t W = crc_stride_w((uint32_t)slots, l);
             m.afrag = d_crc_afrag4; m.afb = d_crc_afb + (size_t)l * 64 * 4; m.stride_waves = W;
+            if (use_partials && W / 4 <= cap_wg) { m.partials = partials; *n_partials = W / 4; }
+            else if (use_partials) HIPCHK(hipMemsetAsync(acc, 0, 8, s));      // (cannot happen with the scratch size t3hip_frame_record_scratch_bytes asks for)
             hipLaunchKernelGGL(crc_fp4_kernel, dim3(W / 4), dim3(256), 0, s, m);
         }
         HIPCHK(hipGetLastError());
@@ -855,17 +865,19 @@ static int launch_crc(const uint8_t* d_data, uint64_t n_bytes, uint32_t* acc, hi
     return T3_OK;
 }
 
-uint64_t t3hip_frame_record_scratch_bytes(uint64_t) { return 64; }
+uint64_t t3hip_frame_record_scratch_bytes(uint64_t) { return 64 + 8ull * kRecordPartialWgs; }   // two accumulators | one (xor, sum) per CRC workgroup; 64 bytes still work (accumulators + atomics)
 int t3hip_frame_record_dev(const void* d_words, uint64_t n_words, uint64_t frame_idx, const t3_cfg* cfg, t3_frame_record* d_rec,
                            void* d_scratch, uint64_t scratch_bytes, void* stream) {
     if (!api_ready()) return T3_E_NODEVICE;
     if (!cfg || !d_rec || (n_words && !d_words) || !d_scratch || scratch_bytes < 8) return T3_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     const uint64_t n_bytes = 9 * n_words; uint64_t tail_off = n_bytes;
-    { const int rc = launch_crc((const uint8_t*)d_words, n_bytes, (uint32_t*)d_scratch, s, &tail_off); if (rc) return rc; }
+    uint32_t* parts = scratch_bytes >= 64 + 8 ? (uint32_t*)((uint8_t*)d_scratch + 64) : nullptr; uint32_t n_parts = 0;
+    const uint32_t cap_wg = parts ? (uint32_t)std::min<uint64_t>((scratch_bytes - 64) / 8, kRecordPartialWgs) : 0u;
+    { const int rc = launch_crc((const uint8_t*)d_words, n_bytes, (uint32_t*)d_scratch, s, &tail_off, parts, cap_wg, &n_parts); if (rc) return rc; }
     hipLaunchKernelGGL(frame_record_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*)d_scratch, crc_lead(n_bytes),
                        tail_off < n_bytes ? (const uint8_t*)d_words + tail_off : (const uint8_t*)nullptr, (uint32_t)(n_bytes - tail_off), (const uint32_t*)d_zpow,
-                       (const uint8_t*)d_words, n_words, frame_idx, (uint32_t)cfg->profile, (uint32_t)cfg->mode, (void*)d_rec);
+                       (const uint8_t*)d_words, n_words, frame_idx, (uint32_t)cfg->profile, (uint32_t)cfg->mode, (void*)d_rec, (const uint32_t*)parts, n_parts);
     HIPCHK(hipGetLastError()); return T3_OK;
 }
 

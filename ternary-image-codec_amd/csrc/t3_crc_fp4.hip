@@ -142,8 +142,8 @@ __global__ __launch_bounds__(256) void crc_fp4_kernel(const CrcMArgs a) {
     if (threadIdx.x == 0) {
         uint32_t x = 0, t = 0;
         for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) { x ^= red[2 * w]; t += red[2 * w + 1]; }
-        if (x) atomicXor(a.chunk_crc, x);
-        if (t) atomicAdd(a.sym_sum, t);
+        if (a.partials) { a.partials[2u * blockIdx.x] = x; a.partials[2u * blockIdx.x + 1u] = t; }
+        else { if (x) atomicXor(a.chunk_crc, x); if (t) atomicAdd(a.sym_sum, t); }
     }
 }
 

@@ -49,6 +49,7 @@ struct CrcMArgs {
     const uint32_t* afrag;                       // [22][64][4]: 16 data slices, the feedback slice, five "append 64 * 2^b bytes" slices, in MFMA lane order
     const uint32_t* zpow;
     uint32_t* chunk_crc; uint32_t* sym_sum;
+    uint32_t* partials;                          // FP4 kernel, != null: workgroup g stores its (xor, sum) at [2 g], [2 g + 1] instead of adding to the two accumulators (no zeroing pass, no atomics)
 };
 
 // Fused FIXED-mode decoder (uniform k, 1-D, no beacon): one tile = 9 bands x nb blocks -> a word-aligned slice of the
@@ -196,7 +197,7 @@ __global__ void crc_chunks_kernel(const CrcArgs a);
 __global__ void crc_mfma_kernel(const CrcMArgs a);
 __global__ void crc_fp4_kernel(const CrcMArgs a);          // the same on the FP4 matrix instruction (t3_crc_fp4.hip); afrag = [14][64][4] FP4 slices
 __global__ void frame_record_kernel(const uint32_t* acc, uint32_t lead, const uint8_t* tail, uint32_t tail_len, const uint32_t* zpow,
-                                    const uint8_t* words, uint64_t n_words, uint64_t frame_idx, uint32_t profile, uint32_t mode, void* rec);
+                                    const uint8_t* words, uint64_t n_words, uint64_t frame_idx, uint32_t profile, uint32_t mode, void* rec, const uint32_t* partials, uint32_t n_partials);
 #endif
 
 }  // namespace t3

@@ -232,7 +232,8 @@ __global__ void hdr_compare_kernel(const uint8_t* in, const HdrExpect expect, ui
 // and the pieces are joined by a butterfly of "append 32 * 2^l zero bytes" operators -- it sits at the end of the stream, so its
 // remainder needs no further shift.
 __global__ __launch_bounds__(64) void frame_record_kernel(const uint32_t* acc, uint32_t lead, const uint8_t* tail, uint32_t tail_len, const uint32_t* zpow,
-                                                          const uint8_t* words, uint64_t n_words, uint64_t frame_idx, uint32_t profile, uint32_t mode, void* recv) {
+                                                          const uint8_t* words, uint64_t n_words, uint64_t frame_idx, uint32_t profile, uint32_t mode, void* recv,
+                                                          const uint32_t* partials, uint32_t n_partials) {   // n_partials != 0: the CRC kernel left one (xor, sum) per workgroup instead of acc[0..1]
     t3_frame_record* rec = (t3_frame_record*)recv;
     const uint32_t lane = threadIdx.x;
     uint32_t r = 0, sum = 0;
@@ -255,9 +256,14 @@ __global__ __launch_bounds__(64) void frame_record_kernel(const uint32_t* acc, u
         }
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
     }
+    uint32_t ax = 0, as = 0;
+    if (n_partials) {
+        for (uint32_t i = lane; i < n_partials; i += 64u) { const uint2 v = *(const uint2*)(partials + 2u * i); ax ^= v.x; as += v.y; }
+        for (int o = 32; o > 0; o >>= 1) { ax ^= __shfl_down(ax, o); as += __shfl_down(as, o); }
+    } else if (lane == 0) { ax = acc[0]; as = acc[1]; }
     if (lane == 0) {
         rec->frame_idx = frame_idx; rec->n_words = n_words; rec->byte_offset = 0;
-        rec->crc32 = (lead ^ acc[0] ^ r) ^ 0xFFFFFFFFu; rec->sym_sum = acc[1] + sum;      // final inversion
+        rec->crc32 = (lead ^ ax ^ r) ^ 0xFFFFFFFFu; rec->sym_sum = as + sum;              // final inversion
         rec->profile = (uint8_t)profile; rec->mode = (uint8_t)mode;
         for (int i = 0; i < 8; ++i) rec->pad_[i] = 0;
     }

@@ -385,13 +385,15 @@ def test_frame_record(gpu, orc, crc_kernel, monkeypatch):
     for n in (0, 1, 6, 255, 256, 257, 100000) + tuple(range(14564, 14564 + 228, 19)) + (14564 + 227, 16384, 20766726 // 64, 1000003, 3000001):   # (the FP4 kernel strides its rounds over 16 .. 2048 waves by size)
         w = rng.integers(0, 27, size=(n, 9), dtype=np.uint8)
         d = torch.from_numpy(w).cuda() if n else torch.zeros(16, dtype=torch.uint8, device="cuda")
-        rec = torch.zeros(gpu.FRAME_RECORD_BYTES, dtype=torch.uint8, device="cuda"); scr = torch.zeros(64, dtype=torch.uint8, device="cuda")
-        gpu.frame_record_dev(d.data_ptr(), n, 7, gpu.make_cfg(profile=2, uep=2), rec.data_ptr(), scr.data_ptr())
-        torch.cuda.synchronize()
-        r = gpu.index_assemble(rec.cpu().numpy(), 100)[0]
-        assert (r.frame_idx, r.n_words, r.byte_offset, r.profile) == (7, n, 100, 2)
-        assert r.crc32 == orc.crc32(w) and r.sym_sum == orc.sym_sum(w)
-        assert list(r.header_syms)[: min(54, 9 * n)] == list(w.reshape(-1)[:54])
+        # scratch of 64 bytes: two accumulators (fill kernel + atomics); of the size the library asks for: one partial per CRC workgroup
+        for nscr in (64, gpu.frame_record_scratch_bytes(n)):
+            rec = torch.zeros(gpu.FRAME_RECORD_BYTES, dtype=torch.uint8, device="cuda"); scr = torch.full((nscr,), 0xA5, dtype=torch.uint8, device="cuda")
+            gpu.frame_record_dev(d.data_ptr(), n, 7, gpu.make_cfg(profile=2, uep=2), rec.data_ptr(), scr.data_ptr(), nscr)
+            torch.cuda.synchronize()
+            r = gpu.index_assemble(rec.cpu().numpy(), 100)[0]
+            assert (r.frame_idx, r.n_words, r.byte_offset, r.profile) == (7, n, 100, 2)
+            assert r.crc32 == orc.crc32(w) and r.sym_sum == orc.sym_sum(w)
+            assert list(r.header_syms)[: min(54, 9 * n)] == list(w.reshape(-1)[:54])
 
 
 # ---- subword trit streams and wire packings -----------------------------------------------------------
