@@ -54,6 +54,19 @@ uint32_t synd_lut_bytes[4] = {0, 0, 0, 0};      // (a size, the same for every c
 int k_index(int k) { return k == 24 ? 0 : k == 22 ? 1 : k == 20 ? 2 : k == 18 ? 3 : -1; }
 DevDiv to_dev(FastDiv f) { return DevDiv{f.mul, f.sh, f.d}; }
 
+// The streaming entry's header check (t3hip_decode_frame_async): pending until a decode path either takes it into its own launch (the pixel
+// kernel with tile tickets: decode_fixed_fused) or launches hdr_compare_kernel in front of its kernels (hdr_flush) -- either way before
+// anything counts failures into verdict[1].
+struct HdrPending { HdrExpect ex; uint32_t hs; uint32_t* verdict; const uint8_t* in; bool pending; };
+static thread_local HdrPending tl_hdr = {{}, 0, nullptr, nullptr, false};
+static int hdr_flush(hipStream_t s) {
+    if (!tl_hdr.pending) return T3_OK;
+    tl_hdr.pending = false;
+    hipLaunchKernelGGL(hdr_compare_kernel, dim3(1), dim3(128), 0, s, tl_hdr.in, tl_hdr.ex, tl_hdr.hs, tl_hdr.verdict);   // also zeroes the block counter
+    HIPCHK(hipGetLastError());
+    return T3_OK;
+}
+
 // Fused FIXED decode (t3_decode_fused.hip): uniform k, 1-D, no beacon.  Returns T3_OK after launching, or 1 if not applicable.
 // The lazily built device tables below are shared by every caller thread of a context, and so are the pinned host mailboxes of the
 // synchronous entry points: both locks live in the context (api_tab_mutex / api_mail_mutex), two contexts never share one.
@@ -216,6 +229,14 @@ int decode_fixed_fused(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_sy
     if (to_pixels) {   // dynamic tile tickets (decode_fixed_px_kernel); T3HIP_STATIC_TILES: measurement knob
         static const bool off = getenv("T3HIP_STATIC_TILES") != nullptr;
         a.tile_ctr = off ? nullptr : api_ticket_counters(s, 1); a.n_classes = std::min<uint32_t>(8u, grid);
+    }
+    if (tl_hdr.pending) {
+        static const bool no_fold = getenv("T3HIP_HDR_KERNEL") != nullptr;                    // measurement / test knob: the separate header kernel
+        if (to_pixels && a.tile_ctr && !no_fold && tile_lo == 0 && tile_hi == 0xFFFFFFFFu && tl_hdr.hs <= 96u && ((uintptr_t)tl_hdr.in & 3u) == 0) {
+            tl_hdr.pending = false;
+            a.verdict = tl_hdr.verdict; a.hdr_in = tl_hdr.in; a.hdr_n = tl_hdr.hs; memcpy(a.hx, tl_hdr.ex.b, 96);
+            a.fail = a.tile_ctr + 64u * a.n_classes + 16u;                                    // library-owned, zero between launches; the last workgroup moves it to verdict[1]
+        } else { const int rc = hdr_flush(s); if (rc) return rc; }
     }
     void* args[] = {(void*)&a};
     HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(to_pixels ? T3_DEC_PX_THREADS : 512), args, a.lds_bytes, s));
@@ -475,6 +496,7 @@ int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_r
                     body = (const uint8_t*)d_b; body_bytes = L.body_syms; hs = 0;
                 }
                 if (!bcn_ok) frc = decode_fixed_fused(body, body_bytes, hs, L, sc, d_out, funits, to_pixels, d_fail, s);
+                if (frc == 1) { const int hrc = hdr_flush(s); if (hrc) return hrc; }   // the other paths: header kernel in front
                 if (frc == 1 && want_rgb) return 1;
                 if (frc == 1 && to_pixels == 1) frc = decode_fixed_uep(body, body_bytes, hs, cfg, L, sc, d_out, funits, d_fail, s);
                 if (frc == 1) frc = decode_fixed_stream(body, body_bytes, hs, cfg, L, sc, d_out, funits, to_pixels, d_fail, s);
@@ -484,6 +506,7 @@ int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_r
         }
     }
     if (want_rgb) return 1;
+    { const int hrc = hdr_flush(s); if (hrc) return hrc; }
     a.total_blocks = total;
     const uint64_t units = to_pixels ? 2 * n_words : n_words;
     *n_out = units;
@@ -613,11 +636,11 @@ int t3hip_decode_frame_async(const void* d_in, uint64_t n_in, const t3_cfg* cfg,
     if (9 * n_in < hs) return T3_E_HEADER;
     // the expected header symbols travel as a kernel argument (96 bytes): nothing to allocate, no limit on how many different
     // headers a long-lived process may see
-    HdrExpect ex; memcpy(ex.b, hdr, 96);
-    hipLaunchKernelGGL(hdr_compare_kernel, dim3(1), dim3(128), 0, s, (const uint8_t*)d_in, ex, hs, d_verdict);   // also zeroes the block counter
-    HIPCHK(hipGetLastError());
+    memcpy(tl_hdr.ex.b, hdr, 96); tl_hdr.hs = hs; tl_hdr.verdict = d_verdict; tl_hdr.in = (const uint8_t*)d_in; tl_hdr.pending = true;
     const ScrCycle sc = scrambler_cycle(cfg->seed_a, cfg->seed_b, cfg->seed_s0);
-    return decode_body(d_in, n_in, *cfg, n_raw, sc.next, d_out, cap, n_out, to_pixels, d_verdict + 1, s);
+    rc = decode_body(d_in, n_in, *cfg, n_raw, sc.next, d_out, cap, n_out, to_pixels, d_verdict + 1, s);
+    if (tl_hdr.pending) { tl_hdr.pending = false; if (rc == T3_OK) rc = T3_E_ARG; }       // (every decode path takes or flushes it; a path that forgot would leave the verdict unwritten)
+    return rc;
 }
 
 int t3hip_decode_profile_dev(const void* d_in, uint64_t n_in, t3_cfg* seen, void* d_out, uint64_t cap, uint64_t* n_out, int to_pixels, void* stream) {

@@ -119,6 +119,10 @@ struct DecFx2Args {
     uint32_t band_blocks[9]; uint64_t band_body_off[9]; uint32_t band_boff6[9];
     uint32_t cyc24, pre0, pre1;
     uint32_t* tile_ctr; uint32_t n_classes;    // px kernel: dynamic tile tickets (n_classes counters + a done counter, 256 B apart; zero between launches); null = static stride
+    // px kernel with tickets, streaming entry (t3hip_decode_frame_async): the header check and the verdict words in the same launch.  verdict != null:
+    // workgroup 0 compares the stream's first hdr_n bytes (hdr_in, 16-byte aligned) with hx and writes verdict[0]; `fail` then points at a library-owned
+    // counter beside the tickets (zero between launches) and the workgroup that finishes last moves it to verdict[1] and re-zeroes it
+    uint32_t* verdict; const uint8_t* hdr_in; uint32_t hdr_n; uint32_t hx[24];
     uint32_t pat[48], pat_off;                 // twelve 16-byte rows: byte q of row r < 11 = 27 x scrambler state of a position of class (r + q) mod 6; row 11: the stream's first block (pre-period states in bytes 0, 1)
     uint32_t y_off, y_stride, q_off, q_stride, o_off, af_off, lds_bytes;   // px kernel: two symbol buffers / queues, y_stride / q_stride apart
     uint32_t bcn_slot, bcn_pb; DevDiv bcn_div;   // BCN kernels: a beacon symbol sits in front of body byte bcn_slot + j bcn_pb (bcn_pb = 9 period - 1 >= 17); `in` is the framed stream

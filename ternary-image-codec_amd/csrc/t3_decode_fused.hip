@@ -184,6 +184,18 @@ __global__ __launch_bounds__(T3_DEC_PX_THREADS, T3_DEC_WAVES_PER_EU) void decode
 #ifdef T3_DEC_STAMPS
     uint64_t st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime(), st_t0 = st_prev, st_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    if (a.verdict && blockIdx.x == 0u && wave == 2u * NW - 1u) {                      // the header check (hdr_compare_kernel's job), by a wave that starts idle
+        uint32_t want = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 24; ++q) want = lane == q ? a.hx[q] : want;           // (kernel arguments are not indexed dynamically)
+        bool mis = false;
+        if (4u * lane < a.hdr_n) {
+            const uint32_t nb = min(4u, a.hdr_n - 4u * lane), mask = nb >= 4u ? 0xFFFFFFFFu : (1u << (8u * nb)) - 1u;
+            mis = ((((const uint32_t*)a.hdr_in)[lane] ^ want) & mask) != 0u;
+        }
+        const bool any = __builtin_amdgcn_ballot_w64(mis) != 0;
+        if (lane == 0) a.verdict[0] = any ? 1u : 0u;
+    }
     const uint8_t* body = a.in + a.hdr_syms;
     const uint32_t n_items = 9u * a.nb;
     const uint32_t units_tile = (a.TS / 13u) * 3u;                                  // pixels per tile
@@ -280,9 +292,11 @@ __global__ __launch_bounds__(T3_DEC_PX_THREADS, T3_DEC_WAVES_PER_EU) void decode
             prev = cur; cur = nxt; nxt = __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + kFx2Next + 4u * (k & 1u)));
         }
     }
+    if (a.verdict) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // every wave's failure counts have arrived before the workgroup reports itself done
     if (dyn && tid == 0u) {                                                          // re-arm the counters for the next launch on this stream: whoever finishes last
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (atomicAdd(a.tile_ctr + 64u * NC, 1u) == grid - 1u) {
+            if (a.verdict) a.verdict[1] = atomicExch(a.fail, 0u);                    // uncorrectable blocks of the whole launch (every other workgroup's counts precede its done count)
             for (uint32_t c = 0; c <= NC; ++c) __hip_atomic_store(a.tile_ctr + 64u * c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
