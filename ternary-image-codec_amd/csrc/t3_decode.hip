@@ -244,8 +244,14 @@ __global__ __launch_bounds__(64) void frame_record_kernel(const uint32_t* acc, u
     }
     if (tail && tail_len) {
         const int32_t lo = (int32_t)tail_len - 32 * (int32_t)(64u - lane);
-        for (int32_t i = lo < 0 ? 0 : lo; i < lo + 32; ++i) {
-            const uint32_t v = tail[i]; sum += v; r ^= v;
+        // the lane's 32 bytes first, all loads in flight together (one after the other, each behind the previous byte's eight register
+        // steps, they were 32 memory latencies in a row: 6 of the kernel's 9 us); bytes in front of the tail read as zero
+        uint32_t bytes[32];
+#pragma unroll
+        for (int32_t i = 0; i < 32; ++i) bytes[i] = lo + i >= 0 ? (uint32_t)tail[lo + i] : 0u;
+#pragma unroll
+        for (int32_t i = 0; i < 32; ++i) {
+            const uint32_t v = bytes[i]; sum += v; r ^= v;                                // (leading zero bytes leave a zero register zero)
 #pragma unroll
             for (int q = 0; q < 8; ++q) r = (r & 1u) ? (0xEDB88320u ^ (r >> 1)) : (r >> 1);
         }
