@@ -86,7 +86,7 @@ struct DecFxArgs {
 //   decode_fixed_kernel     (raw words out) the phases run one after the other (sets | queue | words staged in LDS).
 //                           LDS: [hdr 0][fold tables 3072][T32 3584][FMA][A operand][Y][Q][words]
 // hdr: band rows 0..143, queue counters 160/164, consumer rendezvous 168, give-up flag 172, ticket slots 176/180, small byte tables 192, dummy 384..511
-constexpr int kFx2Cnt = 160, kFx2Sync = 168, kFx2Abort = 172, kFx2Next = 176, kFx2Small = 192;   // kFx2Next: two words, the ticket slot of each barrier parity
+constexpr int kFx2Cnt = 160, kFx2Sync = 168, kFx2Abort = 172, kFx2Next = 176, kFx2FailWg = 184, kFx2Small = 192;   // kFx2Next: two words, the ticket slot of each barrier parity
 // Geometry of the pixel kernel (decode_fixed_px_kernel): threads per workgroup (half producer, half consumer waves), bank copies of
 // its T table, blocks per band per tile, queue capacity.  Measured in round 3 (profiles/r03/notes.md): 768 threads x two workgroups per
 // CU with 32 conflict-free T copies and 78 blocks per band (-DT3_DEC_PX_THREADS=768 -DT3_DEC_PX_TCOP=32 -DT3_DEC_PX_NB=78

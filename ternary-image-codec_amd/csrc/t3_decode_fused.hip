@@ -178,6 +178,10 @@ __global__ __launch_bounds__(T3_DEC_PX_THREADS, T3_DEC_WAVES_PER_EU) void decode
     uint32_t* const ctr = a.tile_ctr + 64u * cls;
     auto draw = [&]() -> uint32_t { return cls + NC * (wgc + atomicAdd(ctr, 1u)); };
     if (tid == 0) *(uint32_t*)(lds + kFx2Next + 4u) = dyn ? draw() : blockIdx.x + grid;   // tile 1 (slot of parity 1; read behind the barrier below)
+    // verdict in this launch: uncorrectable blocks are counted in LDS and the workgroup adds its sum to the launch's counter once, in front of its
+    // done count (global atomics from every wave would have to be waited for -- together with the wave's last pixel stores -- before that count)
+    uint32_t* const failp = a.verdict ? (uint32_t*)(lds + kFx2FailWg) : a.fail;
+    if (tid == 0) *(uint32_t*)(lds + kFx2FailWg) = 0u;
     stage_tables<TCOP, TBASE, MT>(a, tid, blockDim.x);
     if constexpr (RGB) { if (tid < 82u) *(uint32_t*)(lds + a.dq_off + 4u * tid) = ((const uint32_t*)a.dq)[tid]; }     // yd[244] | cd[84]
     __syncthreads();
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(T3_DEC_PX_THREADS, T3_DEC_WAVES_PER_EU) void decode
                     const Synd sA = fx2_set<R, TCOP, TBASE, MT>(bA, LA, lane, a.af_off, a.pat_off);
                     Synd sB; sB.lo = 0; sB.hi = 0;
                     if (wave * 128u + pass * 64u + 32u < n_items) sB = fx2_set<R, TCOP, TBASE, MT>(bB, LB, lane, a.af_off, a.pat_off);
-                    fx2_own_blocks<R>(a.roots, a.fma_off, a.fail, sA, sB, bA, bB, (h ? gB : gA) & 0xFFFFu, lane, kFx2Cnt + 4u * buf, q_off, QCAP);
+                    fx2_own_blocks<R>(a.roots, a.fma_off, failp, sA, sB, bA, bB, (h ? gB : gA) & 0xFFFFu, lane, kFx2Cnt + 4u * buf, q_off, QCAP);
                 }
             }
             if (tid == 0u) *(uint32_t*)(lds + kFx2Next + 4u * buf) = dyn ? cls + NC * (wgc + raw) : nxt + grid;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(T3_DEC_PX_THREADS, T3_DEC_WAVES_PER_EU) void decode
                 const uint32_t tile = prev, buf = (k - 1u) & 1u;
                 const uint32_t y_off = a.y_off + buf * a.y_stride, q_off = a.q_off + buf * a.q_stride;
                 const uint32_t Q = min(*(const uint32_t*)(lds + kFx2Cnt + 4u * buf), QCAP);
-                for (uint32_t e0 = cw * 64u; e0 < Q; e0 += 64u * NW) { const uint32_t e = e0 + lane; if (e < Q) fx2_queue_entry<R>(a.roots, a.fma_off, a.fail, e, q_off, QCAP, y_off); }
+                for (uint32_t e0 = cw * 64u; e0 < Q; e0 += 64u * NW) { const uint32_t e = e0 + lane; if (e < Q) fx2_queue_entry<R>(a.roots, a.fma_off, failp, e, q_off, QCAP, y_off); }
                 T3D_STAMP(2);
                 // rendezvous of the consumer waves: every patch is in LDS before any wave converts symbols
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(T3_DEC_PX_THREADS, T3_DEC_WAVES_PER_EU) void decode
                     uint32_t spins = 0;
                     while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NW * k) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1u << 22)) { if (lane == 0) { *(uint32_t*)(lds + kFx2Abort) = 1u; atomicAdd(a.fail, 1u << 20); } break; }   // never seen; a bound, not a path
+                        if (++spins > (1u << 22)) { if (lane == 0) { *(uint32_t*)(lds + kFx2Abort) = 1u; atomicAdd(failp, 1u << 20); } break; }   // never seen; a bound, not a path
                     }
                 }
                 if (tid == 64u * NW) *(uint32_t*)(lds + kFx2Cnt + 4u * buf) = 0;         // every consumer has read Q; the producers touch this counter after the barrier
@@ -292,8 +296,8 @@ __global__ __launch_bounds__(T3_DEC_PX_THREADS, T3_DEC_WAVES_PER_EU) void decode
             prev = cur; cur = nxt; nxt = __builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + kFx2Next + 4u * (k & 1u)));
         }
     }
-    if (a.verdict) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // every wave's failure counts have arrived before the workgroup reports itself done
     if (dyn && tid == 0u) {                                                          // re-arm the counters for the next launch on this stream: whoever finishes last
+        if (a.verdict) { const uint32_t wgf = *(const uint32_t*)(lds + kFx2FailWg); if (wgf) atomicAdd(a.fail, wgf); }   // (every count precedes the loops' closing barrier)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (atomicAdd(a.tile_ctr + 64u * NC, 1u) == grid - 1u) {
             if (a.verdict) a.verdict[1] = atomicExch(a.fail, 0u);                    // uncorrectable blocks of the whole launch (every other workgroup's counts precede its done count)
