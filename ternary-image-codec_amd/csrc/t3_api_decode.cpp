@@ -373,6 +373,14 @@ int decode_fixed_uep(const uint8_t* body, uint64_t body_bytes, uint32_t hdr_syms
     const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(a.n_tiles, (uint32_t)(api_n_cu() * occ)));
     static const bool st = getenv("T3HIP_STATIC_TILES") != nullptr;
     a.tile_ctr = st ? nullptr : api_ticket_counters(s, 2); a.n_classes = std::min<uint32_t>(8u, grid);
+    if (tl_hdr.pending) {                                                                     // streaming entry: header check + verdict in this launch (as decode_fixed_fused)
+        static const bool no_fold = getenv("T3HIP_HDR_KERNEL") != nullptr;
+        if (a.tile_ctr && !no_fold && tl_hdr.hs <= 96u && ((uintptr_t)tl_hdr.in & 3u) == 0) {
+            tl_hdr.pending = false;
+            a.verdict = tl_hdr.verdict; a.hdr_in = tl_hdr.in; a.hdr_n = tl_hdr.hs; memcpy(a.hx, tl_hdr.ex.b, 96);
+            a.fail = a.tile_ctr + 64u * a.n_classes + 16u;
+        } else { const int rc = hdr_flush(s); if (rc) return rc; }
+    }
     void* args[] = {(void*)&a};
     HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(512), args, a.lds_bytes, s));
     HIPCHK(hipLaunchKernel((const void*)uep_edge_kernel, dim3((3u * a.n_tiles + 1u + 255u) / 256u), dim3(256), args, 0, s));
@@ -496,9 +504,9 @@ int decode_body(const void* d_in, uint64_t n_in, const t3_cfg& cfg, uint64_t n_r
                     body = (const uint8_t*)d_b; body_bytes = L.body_syms; hs = 0;
                 }
                 if (!bcn_ok) frc = decode_fixed_fused(body, body_bytes, hs, L, sc, d_out, funits, to_pixels, d_fail, s);
-                if (frc == 1) { const int hrc = hdr_flush(s); if (hrc) return hrc; }   // the other paths: header kernel in front
-                if (frc == 1 && want_rgb) return 1;
+                if (frc == 1 && want_rgb) { const int hrc = hdr_flush(s); return hrc ? hrc : 1; }
                 if (frc == 1 && to_pixels == 1) frc = decode_fixed_uep(body, body_bytes, hs, cfg, L, sc, d_out, funits, d_fail, s);
+                if (frc == 1) { const int hrc = hdr_flush(s); if (hrc) return hrc; }   // the other paths: header kernel in front
                 if (frc == 1) frc = decode_fixed_stream(body, body_bytes, hs, cfg, L, sc, d_out, funits, to_pixels, d_fail, s);
             }
             if (frc == T3_OK) { *n_out = funits; return T3_OK; }

@@ -148,6 +148,7 @@ struct DecUepArgs {
     uint32_t pat[48], pat_off, rec_off;
     uint32_t y_off, y_stride, q_off, q_stride, lds_bytes;
     uint32_t* tile_ctr; uint32_t n_classes;
+    uint32_t* verdict; const uint8_t* hdr_in; uint32_t hdr_n; uint32_t hx[24];   // header check + verdict words in this launch (as DecFx2Args)
     uint32_t il_on, il_w, il_A; DevDiv div_A, div_w;
     uint8_t* edge;                             // global scratch, n_sym bytes, written sparsely: the symbols of the triples the runs' ends cut through
 };

@@ -94,14 +94,14 @@ __device__ __forceinline__ void px3_from_syms(const uint32_t* s, uint16_t* o) {
 template <int R, int RM>
 __device__ __forceinline__ void uep_pass(const DecUepArgs& a, const Geo gA, const Geo gB, const uint32_t offA, const uint32_t offB, const bool vA, const bool vB, const bool haveB,
                                          const uint32_t u2, const uint32_t y_off, const uint32_t (&LA)[4], const uint32_t (&LB)[4], const uint32_t lane,
-                                         const uint32_t af_off, const uint32_t* __restrict__ roots, const uint32_t cnt_addr, const uint32_t q_off, const uint32_t q_cap) {
+                                         const uint32_t af_off, const uint32_t* __restrict__ roots, const uint32_t cnt_addr, const uint32_t q_off, const uint32_t q_cap, uint32_t* const failp) {
     constexpr uint32_t TCOP = 16, TBASE = kFx2TPx, MT = kFx2ModPx;
     const uint32_t h = lane >> 5;
     const Blk bA = fx2_block(gA, offA, vA, u2, y_off), bB = fx2_block(gB, offB, vB, u2, y_off);
     const Synd sA = fx2_set<R, TCOP, TBASE, MT, 0, RM>(bA, LA, lane, af_off, a.pat_off);
     Synd sB; sB.lo = 0; sB.hi = 0;
     if (haveB) sB = fx2_set<R, TCOP, TBASE, MT, 0, RM>(bB, LB, lane, af_off, a.pat_off);
-    fx2_own_blocks<R>(roots, a.fma_off, a.fail, sA, sB, bA, bB, (h ? gB : gA) & 0xFFFFu, lane, cnt_addr, q_off, q_cap);
+    fx2_own_blocks<R>(roots, a.fma_off, failp, sA, sB, bA, bB, (h ? gB : gA) & 0xFFFFu, lane, cnt_addr, q_off, q_cap);
 }
 }  // namespace
 
@@ -117,6 +117,21 @@ __global__ __launch_bounds__(512, 6) void decode_uep_px_kernel(const DecUepArgs 
     const uint32_t wgc = (grid - cls + NC - 1u) / NC;
     uint32_t* const ctr = a.tile_ctr + 64u * cls;
     if (tid == 0) *(uint32_t*)(lds + kFx2Next + 4u) = dyn ? cls + NC * (wgc + atomicAdd(ctr, 1u)) : blockIdx.x + grid;
+    // header check and verdict words in this launch (streaming entry; as decode_fixed_px_kernel): failures counted in LDS, one global add per workgroup
+    uint32_t* const failp = a.verdict ? (uint32_t*)(lds + kFx2FailWg) : a.fail;
+    if (tid == 0) *(uint32_t*)(lds + kFx2FailWg) = 0u;
+    if (a.verdict && blockIdx.x == 0u && wave == 2u * NW - 1u) {
+        uint32_t want = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 24; ++q) want = lane == q ? a.hx[q] : want;
+        bool mis = false;
+        if (4u * lane < a.hdr_n) {
+            const uint32_t nb = min(4u, a.hdr_n - 4u * lane), mask = nb >= 4u ? 0xFFFFFFFFu : (1u << (8u * nb)) - 1u;
+            mis = ((((const uint32_t*)a.hdr_in)[lane] ^ want) & mask) != 0u;
+        }
+        const bool any = __builtin_amdgcn_ballot_w64(mis) != 0;
+        if (lane == 0) a.verdict[0] = any ? 1u : 0u;
+    }
     // ---- constants -> LDS ----
     if (tid == 0) {
 #pragma unroll
@@ -219,8 +234,8 @@ __global__ __launch_bounds__(512, 6) void decode_uep_px_kernel(const DecUepArgs 
                     const bool vA = has(gA, oA, tile), vB = has(gB, oB, tile), haveB = pip + 32u < n_items;
                     const uint32_t cnt_addr = kUepCnt + 4u * (2u * buf + pgp), q_off = a.q_off + buf * a.q_stride + q_rel;
                     // (one A operand, group 0's: the code with more parity -- its syndromes include the other code's)
-                    if (pgp == 0u) uep_pass<RA, RA>(a, gA, gB, oA, oB, vA, vB, haveB, u2, y_off, LA, LB, lane, af_off, a.grp[0].roots, cnt_addr, q_off, q_cap);
-                    else uep_pass<RB, RA>(a, gA, gB, oA, oB, vA, vB, haveB, u2, y_off, LA, LB, lane, af_off, a.grp[1].roots, cnt_addr, q_off, q_cap);
+                    if (pgp == 0u) uep_pass<RA, RA>(a, gA, gB, oA, oB, vA, vB, haveB, u2, y_off, LA, LB, lane, af_off, a.grp[0].roots, cnt_addr, q_off, q_cap, failp);
+                    else uep_pass<RB, RA>(a, gA, gB, oA, oB, vA, vB, haveB, u2, y_off, LA, LB, lane, af_off, a.grp[1].roots, cnt_addr, q_off, q_cap, failp);
                 }
             }
             if (tid == 0u) *(uint32_t*)(lds + kFx2Next + 4u * buf) = dyn ? cls + NC * (wgc + raw) : nxt + grid;
@@ -240,7 +255,7 @@ __global__ __launch_bounds__(512, 6) void decode_uep_px_kernel(const DecUepArgs 
             uint32_t spins = 0;
             while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NW * rdv) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 22)) { if (lane == 0) { *(uint32_t*)(lds + kFx2Abort) = 1u; atomicAdd(a.fail, 1u << 20); } break; }   // a bound, not a path
+                if (++spins > (1u << 22)) { if (lane == 0) { *(uint32_t*)(lds + kFx2Abort) = 1u; atomicAdd(failp, 1u << 20); } break; }   // a bound, not a path
             }
         };
         for (uint32_t k = 0;; ++k) {
@@ -257,8 +272,8 @@ __global__ __launch_bounds__(512, 6) void decode_uep_px_kernel(const DecUepArgs 
                     const uint32_t QB = a.n_grp > 1u ? min(__builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + kUepCnt + 4u * (2u * buf + 1u))), capB) : 0u;
                     const uint32_t nA = (QA + 63u) / 64u, nB = (QB + 63u) / 64u;
                     for (uint32_t sl = cw; sl < nA + nB; sl += NW) {
-                        if (sl < nA) { const uint32_t e = 64u * sl + lane; if (e < QA) fx2_queue_entry<RA>(a.grp[0].roots, a.fma_off, a.fail, e, qA, capA, y_off); }
-                        else { const uint32_t e = 64u * (sl - nA) + lane; if (e < QB) fx2_queue_entry<RB>(a.grp[1].roots, a.fma_off, a.fail, e, qB, capB, y_off); }
+                        if (sl < nA) { const uint32_t e = 64u * sl + lane; if (e < QA) fx2_queue_entry<RA>(a.grp[0].roots, a.fma_off, failp, e, qA, capA, y_off); }
+                        else { const uint32_t e = 64u * (sl - nA) + lane; if (e < QB) fx2_queue_entry<RB>(a.grp[1].roots, a.fma_off, failp, e, qB, capB, y_off); }
                     }
                 }
                 rendezvous();                                                       // every patch is in LDS
@@ -335,8 +350,10 @@ __global__ __launch_bounds__(512, 6) void decode_uep_px_kernel(const DecUepArgs 
         }
     }
     if (dyn && tid == 0u) {
+        if (a.verdict) { const uint32_t wgf = *(const uint32_t*)(lds + kFx2FailWg); if (wgf) atomicAdd(a.fail, wgf); }   // (every count precedes the loops' closing barrier)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (atomicAdd(a.tile_ctr + 64u * NC, 1u) == grid - 1u) {
+            if (a.verdict) a.verdict[1] = atomicExch(a.fail, 0u);
             for (uint32_t c = 0; c <= NC; ++c) __hip_atomic_store(a.tile_ctr + 64u * c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
