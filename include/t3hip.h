@@ -248,6 +248,9 @@ int t3hip_inject_errors_dev(void* d_words9, uint64_t first_sym, uint64_t n_block
                             uint32_t seed, int max_err, void* stream);
 
 /* ---- frame index record (multi-GPU exchange payload) -------------------------------- */
+/* d_scratch: device memory the call may use until the record is written (stream-ordered), 4-byte aligned, content irrelevant.
+ * t3hip_frame_record_scratch_bytes() says how much it would like (one partial result per CRC workgroup: no zeroing pass, no atomics);
+ * anything from 8 bytes up works (two accumulators, zeroed by a fill in front of the CRC kernel). */
 int t3hip_frame_record_dev(const void* d_words9, uint64_t n_words, uint64_t frame_idx,
                            const t3_cfg* cfg, t3_frame_record* d_rec, void* d_scratch,
                            uint64_t scratch_bytes, void* stream);
