@@ -213,7 +213,7 @@ __device__ __forceinline__ uint32_t fx2_single(const Synd& sy, const uint32_t yb
 // 2: outside the short routine's conditions (the caller runs fx_correct on this lane).
 // Table index of a + x y = FMA + 729 x + 27 y + a; multiplication commutes, so the operand that is known early carries the
 // factor 729 (and the table base) and the other one the factor 27: one v_add3 per multiply-accumulate.
-template <int R, uint32_t SMB = 0>
+template <int R, uint32_t SMB = 0, bool WIDE = true>
 __device__ __forceinline__ uint32_t fx2_correct(const uint32_t* S, Fix& fx, const uint32_t* __restrict__ root_tbl, const uint32_t FMA) {
     constexpr uint32_t SM = SMB + kFx2Small;
     constexpr int T = R / 2;
@@ -276,37 +276,56 @@ __device__ __forceinline__ uint32_t fx2_correct(const uint32_t* S, Fix& fx, cons
     uint32_t s22 = 0;                                                              // sigma' = sigma1 + 2 sigma2 x (+ sigma4 x^3)
     if constexpr (T >= 2) s22 = tab(FMA + 729u + sg27[2] + sg[2]);
     const uint32_t s22_27 = 27u * s22;
-    // Forney for the (up to) T roots side by side: no branch per root and no early return inside, so the T chains of dependent table reads
-    // (position -> x^-1 -> Omega(x^-1) -> value: seven levels) are issued interleaved instead of one after the other; a lane's unused
-    // slots run on position 0 and are discarded (round 3: the correction is one long chain of LDS round trips, ~170 cycles each)
-    uint32_t r = roots, bad = 0u;
-    uint32_t pe[T], xix[T];
+    if constexpr (WIDE) {
+        // Forney for the (up to) T roots side by side: no branch per root and no early return inside, so the T chains of dependent table reads
+        // (position -> x^-1 -> Omega(x^-1) -> value: seven levels) are issued interleaved instead of one after the other; a lane's unused
+        // slots run on position 0 and are discarded (round 3: the correction is one long chain of LDS round trips, ~170 cycles each)
+        uint32_t r = roots, bad = 0u;
+        uint32_t pe[T], xix[T];
+    #pragma unroll
+        for (int e = 0; e < T; ++e) {
+            const bool have = (uint32_t)e < np;
+            const uint32_t p = have ? (uint32_t)__ffs((int)r) - 1u : 0u; r &= r - 1u;
+            pe[e] = p;
+            xix[e] = __umul24(l8(SM + kFx2EX + (p == 0 ? 0u : 26u - p)), 729u) + FMA;
+        }
+        uint32_t num[T], den[T];
+    #pragma unroll
+        for (int e = 0; e < T; ++e) { num[e] = Om[T - 1]; den[e] = tab(xix[e] + s22_27 + sg[1]); }
+    #pragma unroll
+        for (int q = T - 2; q >= 0; --q) {
+    #pragma unroll
+            for (int e = 0; e < T; ++e) num[e] = tab(xix[e] + 27u * num[e] + Om[q]);
+        }
+        if constexpr (T >= 4) {
+    #pragma unroll
+            for (int e = 0; e < T; ++e) { const uint32_t x2 = tab(xix[e] + sg27[4]); const uint32_t x3 = tab(xix[e] + 27u * x2); den[e] = tab(xix[e] + 27u * x3 + den[e]); }
+        }
+    #pragma unroll
+        for (int e = 0; e < T; ++e) {
+            const bool have = (uint32_t)e < np;
+            bad |= (have && den[e] == 0u) ? 1u : 0u;                                    // OLD:656
+            fx.pos[e] = pe[e]; fx.mag[e] = tab(FMA + 729u * l8(SM + kFx2NEG + num[e]) + 27u * l8(SM + kFx2INV + den[e]));   // OLD:657; FIXED subtracts it
+        }
+        if (bad) return 1u;
+    } else {                                                                       // root by root (the two-code kernel of RS(26,20) + RS(26,22): the wide form costs it a spilled register inside the tile loop)
+        uint32_t r = roots;
 #pragma unroll
-    for (int e = 0; e < T; ++e) {
-        const bool have = (uint32_t)e < np;
-        const uint32_t p = have ? (uint32_t)__ffs((int)r) - 1u : 0u; r &= r - 1u;
-        pe[e] = p;
-        xix[e] = __umul24(l8(SM + kFx2EX + (p == 0 ? 0u : 26u - p)), 729u) + FMA;
+        for (int e = 0; e < T; ++e) {
+            if ((uint32_t)e < np) {
+                const uint32_t p = (uint32_t)__ffs((int)r) - 1u; r &= r - 1u;
+                const uint32_t xi = l8(SM + kFx2EX + (p == 0 ? 0u : 26u - p));
+                const uint32_t xix = __umul24(xi, 729u) + FMA;
+                uint32_t num = Om[T - 1];
+#pragma unroll
+                for (int q = T - 2; q >= 0; --q) num = tab(xix + 27u * num + Om[q]);
+                uint32_t den = tab(xix + s22_27 + sg[1]);
+                if constexpr (T >= 4) { const uint32_t x2 = tab(xix + sg27[4]); const uint32_t x3 = tab(xix + 27u * x2); den = tab(xix + 27u * x3 + den); }
+                if (den == 0) return 1u;                                                // OLD:656
+                fx.pos[e] = p; fx.mag[e] = tab(FMA + 729u * l8(SM + kFx2NEG + num) + 27u * l8(SM + kFx2INV + den));   // OLD:657; FIXED subtracts it
+            }
+        }
     }
-    uint32_t num[T], den[T];
-#pragma unroll
-    for (int e = 0; e < T; ++e) { num[e] = Om[T - 1]; den[e] = tab(xix[e] + s22_27 + sg[1]); }
-#pragma unroll
-    for (int q = T - 2; q >= 0; --q) {
-#pragma unroll
-        for (int e = 0; e < T; ++e) num[e] = tab(xix[e] + 27u * num[e] + Om[q]);
-    }
-    if constexpr (T >= 4) {
-#pragma unroll
-        for (int e = 0; e < T; ++e) { const uint32_t x2 = tab(xix[e] + sg27[4]); const uint32_t x3 = tab(xix[e] + 27u * x2); den[e] = tab(xix[e] + 27u * x3 + den[e]); }
-    }
-#pragma unroll
-    for (int e = 0; e < T; ++e) {
-        const bool have = (uint32_t)e < np;
-        bad |= (have && den[e] == 0u) ? 1u : 0u;                                    // OLD:656
-        fx.pos[e] = pe[e]; fx.mag[e] = tab(FMA + 729u * l8(SM + kFx2NEG + num[e]) + 27u * l8(SM + kFx2INV + den[e]));   // OLD:657; FIXED subtracts it
-    }
-    if (bad) return 1u;
     fx.np = np;
     return 0u;
 }
@@ -377,31 +396,37 @@ __device__ __forceinline__ bool fx2_correct_full(const uint32_t* S, Fix& fx, con
 }
 
 // One queued block: syndromes -> corrections patched into the symbol buffer at yb; returns false for an uncorrectable block.
-template <int R, uint32_t SMB = 0>
+template <int R, uint32_t SMB = 0, bool WIDE = true>
 __device__ __forceinline__ bool fx2_fix_block(const uint32_t lo, const uint32_t hi, const uint32_t yb, const uint32_t* __restrict__ root_tbl, const uint32_t FMA) {
     constexpr uint32_t K = 26 - R, H = R / 2;
     uint32_t S[R];
 #pragma unroll
     for (uint32_t j = 0; j < (uint32_t)R; ++j) S[j] = ((j < H ? lo : hi) >> (8u * (j % H))) & 0xFFu;
     Fix fx; fx.np = 0;
-    uint32_t rc = fx2_correct<R, SMB>(S, fx, root_tbl, FMA);
+    uint32_t rc = fx2_correct<R, SMB, WIDE>(S, fx, root_tbl, FMA);
     if (rc == 2u) rc = fx2_correct_full<R, SMB>(S, fx, root_tbl, FMA) ? 0u : 1u;      // longer register than t: the full-length routine decides
     if (rc != 0u) return false;
-    // the patches side by side as well: a slot that patches nothing (no root, or a parity position) works on the dummy bytes
-    uint32_t ad[R / 2], yv[R / 2];
+    if constexpr (WIDE) {
+        // the patches side by side as well: a slot that patches nothing (no root, or a parity position) works on the dummy bytes
+        uint32_t ad[R / 2], yv[R / 2];
+    #pragma unroll
+        for (int q = 0; q < R / 2; ++q) { ad[q] = ((uint32_t)q < fx.np && fx.pos[q] < K) ? yb + 9u * fx.pos[q] : SMB + kFx2Dummy + 4u * (uint32_t)q; yv[q] = l8(ad[q]); }
+    #pragma unroll
+        for (int q = 0; q < R / 2; ++q) yv[q] = l8(FMA + (54u + fx.mag[q]) * 27u + min(yv[q], 26u));   // y - m = y + 2 m  (dummy bytes may hold anything)
+    #pragma unroll
+        for (int q = 0; q < R / 2; ++q) *T3_LP(uint8_t, ad[q]) = (uint8_t)yv[q];
+    } else {
 #pragma unroll
-    for (int q = 0; q < R / 2; ++q) { ad[q] = ((uint32_t)q < fx.np && fx.pos[q] < K) ? yb + 9u * fx.pos[q] : SMB + kFx2Dummy + 4u * (uint32_t)q; yv[q] = l8(ad[q]); }
-#pragma unroll
-    for (int q = 0; q < R / 2; ++q) yv[q] = l8(FMA + (54u + fx.mag[q]) * 27u + min(yv[q], 26u));   // y - m = y + 2 m  (dummy bytes may hold anything)
-#pragma unroll
-    for (int q = 0; q < R / 2; ++q) *T3_LP(uint8_t, ad[q]) = (uint8_t)yv[q];
+        for (int q = 0; q < R / 2; ++q)
+            if ((uint32_t)q < fx.np && fx.pos[q] < K) { const uint32_t ad = yb + 9u * fx.pos[q]; *T3_LP(uint8_t, ad) = (uint8_t)l8(FMA + (54u + fx.mag[q]) * 27u + l8(ad)); }   // y - m = y + 2 m
+    }
     return true;
 }
 
 // E1 for the 64 blocks two sets leave with a wave (lower half-wave: set A, upper: set B): single errors fixed in place, the other
 // flagged blocks appended to the queue at q_off (syndromes, 8 bytes; block tags, 2 bytes, behind qcap entries); a block that
 // finds the queue full is corrected on the spot.
-template <int R, uint32_t SMB = 0>
+template <int R, uint32_t SMB = 0, bool WIDE = true>
 __device__ __forceinline__ void fx2_own_blocks(const uint32_t* __restrict__ roots, const uint32_t fma_off, uint32_t* fail, const Synd& sA, const Synd& sB, const Blk& bA, const Blk& bB, const uint32_t tag,
                                                const uint32_t lane, const uint32_t cnt_addr, const uint32_t q_off, const uint32_t qcap) {
     const uint32_t h = lane >> 5;
@@ -423,17 +448,17 @@ __device__ __forceinline__ void fx2_own_blocks(const uint32_t* __restrict__ root
             if (__builtin_expect(slot < qcap, 1)) {
                 *T3_LP(u32x2, q_off + 8u * slot) = u32x2{own.lo, own.hi};              // the r syndromes ...
                 *T3_LP(uint16_t, q_off + 8u * qcap + 2u * slot) = (uint16_t)tag;       // ... and the block: where its symbols start in the tile's buffer
-            } else if (!fx2_fix_block<R, SMB>(own.lo, own.hi, yb, roots, fma_off)) atomicAdd(fail, 1u);   // queue full (cold)
+            } else if (!fx2_fix_block<R, SMB, WIDE>(own.lo, own.hi, yb, roots, fma_off)) atomicAdd(fail, 1u);   // queue full (cold)
         }
     }
 }
 
 // BM for queue entry e: the block's symbols are at y_off + tag, tag = band + 9 K (block within the tile)
-template <int R, uint32_t SMB = 0>
+template <int R, uint32_t SMB = 0, bool WIDE = true>
 __device__ __forceinline__ void fx2_queue_entry(const uint32_t* __restrict__ roots, const uint32_t fma_off, uint32_t* fail, const uint32_t e, const uint32_t q_off, const uint32_t qcap, const uint32_t y_off) {
     const u32x2 sy = *T3_LP(const u32x2, q_off + 8u * e);
     const uint32_t tag = *T3_LP(const uint16_t, q_off + 8u * qcap + 2u * e);
-    if (!fx2_fix_block<R, SMB>(sy.x, sy.y, y_off + tag, roots, fma_off)) atomicAdd(fail, 1u);
+    if (!fx2_fix_block<R, SMB, WIDE>(sy.x, sy.y, y_off + tag, roots, fma_off)) atomicAdd(fail, 1u);
 }
 
 }  // namespace

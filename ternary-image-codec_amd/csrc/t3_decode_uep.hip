@@ -91,7 +91,7 @@ __device__ __forceinline__ void px3_from_syms(const uint32_t* s, uint16_t* o) {
 }
 
 // producer work of one (wave, pass): two sets of one group
-template <int R, int RM>
+template <int R, int RM, bool WIDE>
 __device__ __forceinline__ void uep_pass(const DecUepArgs& a, const Geo gA, const Geo gB, const uint32_t offA, const uint32_t offB, const bool vA, const bool vB, const bool haveB,
                                          const uint32_t u2, const uint32_t y_off, const uint32_t (&LA)[4], const uint32_t (&LB)[4], const uint32_t lane,
                                          const uint32_t af_off, const uint32_t* __restrict__ roots, const uint32_t cnt_addr, const uint32_t q_off, const uint32_t q_cap, uint32_t* const failp) {
@@ -101,7 +101,7 @@ __device__ __forceinline__ void uep_pass(const DecUepArgs& a, const Geo gA, cons
     const Synd sA = fx2_set<R, TCOP, TBASE, MT, 0, RM>(bA, LA, lane, af_off, a.pat_off);
     Synd sB; sB.lo = 0; sB.hi = 0;
     if (haveB) sB = fx2_set<R, TCOP, TBASE, MT, 0, RM>(bB, LB, lane, af_off, a.pat_off);
-    fx2_own_blocks<R>(roots, a.fma_off, failp, sA, sB, bA, bB, (h ? gB : gA) & 0xFFFFu, lane, cnt_addr, q_off, q_cap);
+    fx2_own_blocks<R, 0, WIDE>(roots, a.fma_off, failp, sA, sB, bA, bB, (h ? gB : gA) & 0xFFFFu, lane, cnt_addr, q_off, q_cap);
 }
 }  // namespace
 
@@ -109,6 +109,7 @@ __device__ __forceinline__ void uep_pass(const DecUepArgs& a, const Geo gA, cons
 template <int RA, int RB>
 __global__ __launch_bounds__(512, 6) void decode_uep_px_kernel(const DecUepArgs a) {
     constexpr uint32_t NW = 4;                                                       // producer waves = consumer waves
+    constexpr bool WIDE = !(RA == 6 && RB == 4);                                     // Forney chains side by side (t3_decode_fx2.h), except where it costs a spill
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nthr = blockDim.x;
     // ---- tickets (as decode_fixed_px_kernel) ----
     const uint32_t grid = gridDim.x;
@@ -234,8 +235,8 @@ __global__ __launch_bounds__(512, 6) void decode_uep_px_kernel(const DecUepArgs 
                     const bool vA = has(gA, oA, tile), vB = has(gB, oB, tile), haveB = pip + 32u < n_items;
                     const uint32_t cnt_addr = kUepCnt + 4u * (2u * buf + pgp), q_off = a.q_off + buf * a.q_stride + q_rel;
                     // (one A operand, group 0's: the code with more parity -- its syndromes include the other code's)
-                    if (pgp == 0u) uep_pass<RA, RA>(a, gA, gB, oA, oB, vA, vB, haveB, u2, y_off, LA, LB, lane, af_off, a.grp[0].roots, cnt_addr, q_off, q_cap, failp);
-                    else uep_pass<RB, RA>(a, gA, gB, oA, oB, vA, vB, haveB, u2, y_off, LA, LB, lane, af_off, a.grp[1].roots, cnt_addr, q_off, q_cap, failp);
+                    if (pgp == 0u) uep_pass<RA, RA, WIDE>(a, gA, gB, oA, oB, vA, vB, haveB, u2, y_off, LA, LB, lane, af_off, a.grp[0].roots, cnt_addr, q_off, q_cap, failp);
+                    else uep_pass<RB, RA, WIDE>(a, gA, gB, oA, oB, vA, vB, haveB, u2, y_off, LA, LB, lane, af_off, a.grp[1].roots, cnt_addr, q_off, q_cap, failp);
                 }
             }
             if (tid == 0u) *(uint32_t*)(lds + kFx2Next + 4u * buf) = dyn ? cls + NC * (wgc + raw) : nxt + grid;
@@ -272,8 +273,8 @@ __global__ __launch_bounds__(512, 6) void decode_uep_px_kernel(const DecUepArgs 
                     const uint32_t QB = a.n_grp > 1u ? min(__builtin_amdgcn_readfirstlane(*(const uint32_t*)(lds + kUepCnt + 4u * (2u * buf + 1u))), capB) : 0u;
                     const uint32_t nA = (QA + 63u) / 64u, nB = (QB + 63u) / 64u;
                     for (uint32_t sl = cw; sl < nA + nB; sl += NW) {
-                        if (sl < nA) { const uint32_t e = 64u * sl + lane; if (e < QA) fx2_queue_entry<RA>(a.grp[0].roots, a.fma_off, failp, e, qA, capA, y_off); }
-                        else { const uint32_t e = 64u * (sl - nA) + lane; if (e < QB) fx2_queue_entry<RB>(a.grp[1].roots, a.fma_off, failp, e, qB, capB, y_off); }
+                        if (sl < nA) { const uint32_t e = 64u * sl + lane; if (e < QA) fx2_queue_entry<RA, 0, WIDE>(a.grp[0].roots, a.fma_off, failp, e, qA, capA, y_off); }
+                        else { const uint32_t e = 64u * (sl - nA) + lane; if (e < QB) fx2_queue_entry<RB, 0, WIDE>(a.grp[1].roots, a.fma_off, failp, e, qB, capB, y_off); }
                     }
                 }
                 rendezvous();                                                       // every patch is in LDS
