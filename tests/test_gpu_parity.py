@@ -771,6 +771,34 @@ def test_rgb_fused_all_colours(t3, orc, gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tile", [(16, 3), (48, 5), (128, 2), (512, 4), (16, 1), (528, 3), (2048, 2), (4100, 3), (516, 7), (20000, 2)])
+@pytest.mark.parametrize("uep", [2, "luma"])
+def test_2d_in_place_flows(t3, orc, gpu, tile, uep):
+    """Round 3: the 2-D encode flows that reverse odd rows IN PLACE -- rows of whole 16-byte granules up to 512 symbols (whole rows in the symbol
+    buffer), and wider rows that are multiples of 4 (runs placed where they belong, pieces reversed as dword pairs); rows of 516 / 4100
+    symbols take the dword flow with ragged chunks, odd chunk heights restart the row parity inside a tile, the stream's last row is
+    short.  Pixel counts around tile and chunk edges, both arithmetic modes, against the oracle; then the decoder on the same stream."""
+    import torch
+    rng = np.random.default_rng(tile[0] * 31 + tile[1])
+    s = torch.cuda.current_stream().cuda_stream
+    for n in (400_003, 1_200_001):
+        px = rand_pixels(rng, n)
+        for mode in (0, 1):
+            cfg, ocfg = both(gpu, dict(profile=4, uep=uep, tile=tile), mode)
+            rc, want = orc.encode_frame(px, ocfg, cap=n); assert rc == 0
+            n_cap = t3.encoded_words((n + 1) // 2, cfg)
+            d_px = torch.from_numpy(px.view(np.uint8).reshape(-1).copy()).cuda()
+            d_out = torch.zeros(n_cap * 9 + 64, dtype=torch.uint8, device="cuda")
+            assert t3.encode_frame_dev(d_px.data_ptr(), n, cfg, d_out.data_ptr(), n_cap, s) == len(want)
+            torch.cuda.synchronize()
+            got = d_out[: 9 * len(want)].cpu().numpy()
+            assert np.array_equal(got, np.asarray(want).reshape(-1)), (tile, uep, n, mode, np.flatnonzero(got != np.asarray(want).reshape(-1))[:8])
+            if mode == 1:
+                ok, back = gpu.decode_frame(np.asarray(want).reshape(-1, 9), gpu.DecoderContext(mode=1))
+                assert ok and np.array_equal(np.asarray(back)[:n], px), (tile, uep, n)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kw", [dict(profile=4, uep=2, tile=(64, 64)), dict(profile=4, uep="luma", tile=(1024, 16)), dict(profile=4, uep=1, tile=(7, 5)),
                                 dict(profile=1, uep="luma"), dict(profile=2, uep=2, beacon=(64, 4, 1)), dict(profile=1, uep=[0, 1, 2, 3, 0, 1, 2, 3, 0])])
 def test_rgb_fused_other_flows(t3, orc, gpu, kw):
