@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--encode-only", action="store_true", help="profiling aid: skip decode + index in the loop")
     ap.add_argument("--overlap-record", action="store_true", help="index record on a second HIP stream beside the decode (round 1's default; the round-2 decoder leaves the CRC kernel no registers to run beside it, so the record now follows on the main stream)")
     ap.add_argument("--serial", action="store_true", help="(default now) index record on the main stream")
+    ap.add_argument("--event-every", type=int, default=4, help="HIP events around the encode / decode launches on every n-th timed step (the events themselves cost a step 4 us each -- four of them 17 us of 0.29 ms when recorded on every step: --event-every 1)")
     ap.add_argument("--record-first", action="store_true", help="index record right behind the encode whose output it reads instead of behind the decode (measured: the CRC kernel gains 4 us from the warm memory-side cache, the decoder and the encoder lose 3 -- the step is the same)")
     ap.add_argument("--sync-decode", action="store_true", help="every frame through the synchronous decode entry (host-parsed header, two synchronisations per frame)")
     ap.add_argument("--no-verify", action="store_true", help="profiling aid for timing-only ablation builds (results are wrong by construction)")
@@ -342,7 +343,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i, events[i])
+        step(i, events[i] if i % max(args.event_every, 1) == 0 else None)
     if s2 is not None:
         cur.wait_stream(s2)
     ex_ev = (t3.Event(), t3.Event())
@@ -391,8 +392,9 @@ def main():
         if multi:
             dist.destroy_process_group()
         return
-    enc_ms = [events[i][0].elapsed_ms(events[i][1]) for i in range(args.steps)]
-    dec_ms = [events[i][3].elapsed_ms(events[i][2]) for i in range(args.steps)] if not args.encode_only else [float("nan")]
+    ev_steps = [i for i in range(args.steps) if i % max(args.event_every, 1) == 0]
+    enc_ms = [events[i][0].elapsed_ms(events[i][1]) for i in ev_steps]
+    dec_ms = [events[i][3].elapsed_ms(events[i][2]) for i in ev_steps] if not args.encode_only else [float("nan")]
     enc_avg = sum(enc_ms) / len(enc_ms); dec_avg = sum(dec_ms) / len(dec_ms)
     alg_bytes = 6 * NPX + 9 * n_enc                       # read 6 B/px, write 9 B/word = 385,966,134 B
     achieved = alg_bytes / (enc_avg * 1e-3) / 1e9
@@ -406,7 +408,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "one 7680x4320 frame per rank per step (BASELINE configs[1]; %d distinct frames resident per rank, global frame f = rank + N j, LCG seed 12345 + f: configs[3]): fused encode COMPAT P3 RS(26,20) 1-D, then FIXED-mode decode of the same frame with 0..3 injected symbol errors per block (" % FPR + ("synchronous entry, header parsed on the host per frame" if args.sync_decode else "streaming entry: configuration from the stream's first frame, header symbols checked on the device") + "), then index record" + (" [encode only]" if args.encode_only else ""),
-                   "frame_px": NPX, "coded_words": n_enc, "frames_per_rank": FPR, "settle_ms": args.settle_ms, "settle_steps": settle_steps,
+                   "frame_px": NPX, "coded_words": n_enc, "frames_per_rank": FPR, "settle_ms": args.settle_ms, "settle_steps": settle_steps, "event_every": max(args.event_every, 1),
                    "sharding": "frames per rank, no data-path collective; one all-gather of index records per batch", "exchange": exchange_via},
         "exchange_ms": (round(ex_ev[0].elapsed_ms(ex_ev[1]), 4) if (multi and not args.encode_only) else None),
         "exchange_host_ms": (round(exchange_host_ms, 4) if (multi and not args.encode_only) else None),
@@ -416,15 +418,15 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc("pmc_encode_latest.json"),
                      "traffic_source": "profiles/pmc_encode_latest.json: rocprofv3 --pmc passes of this command in their own runs (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024, gfx950 correction), not measured in this run",
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "launch_ms": round(enc_avg, 4),
-                     "note": "north-star kernel (SURVEY 8d); launch_ms = HIP events around the launch inside the timed loop"},
+                     "launch_ms": round(enc_avg, 4), "launch_samples": len(enc_ms),
+                     "note": "north-star kernel (SURVEY 8d); launch_ms = HIP events around the launch inside the timed loop, on every %d-th timed step (an event costs the stream ~4 us; --event-every 1: every step)" % max(args.event_every, 1)},
     }
     if not args.encode_only:      # the decoder is the longer kernel of the step: same definition, SURVEY 8d decode bytes + 6 B/px
         dec_bytes = 9 * n_fenc + 6 * NPX
-        out["roofline_decode"] = {"kernel": "decode_fixed_px_kernel<r=6, pixels>" + (" (+ header read-back and failure-flag sync of the synchronous entry point)" if args.sync_decode else " (+ header check kernel)"),
+        out["roofline_decode"] = {"kernel": "decode_fixed_px_kernel<r=6, pixels>" + (" (+ header read-back and failure-flag sync of the synchronous entry point)" if args.sync_decode else " (header check inside the launch)"),
                                   "bound": "hbm", "achieved": round(dec_bytes / (dec_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(dec_bytes / (dec_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc("pmc_decode_latest.json"), "traffic_source": "profiles/pmc_decode_latest.json (separate rocprofv3 --pmc runs of this command)",
-                                  "algorithmic_bytes_per_launch": dec_bytes, "launch_ms": round(dec_avg, 4)}
+                                  "algorithmic_bytes_per_launch": dec_bytes, "launch_ms": round(dec_avg, 4), "launch_samples": len(dec_ms)}
     if world == 1 and not args.no_verify:                  # reported beside the line, on rank 0 at N=1 only
         if not args.encode_only and not args.no_rgb:
             out["rgb_path"] = rgb_path(t3, orc, torch, dev, cfg, fcfg, stream)
