@@ -191,7 +191,7 @@ def main():
     ap.add_argument("--encode-only", action="store_true", help="profiling aid: skip decode + index in the loop")
     ap.add_argument("--overlap-record", action="store_true", help="index record on a second HIP stream beside the decode (round 1's default; the round-2 decoder leaves the CRC kernel no registers to run beside it, so the record now follows on the main stream)")
     ap.add_argument("--serial", action="store_true", help="(default now) index record on the main stream")
-    ap.add_argument("--event-every", type=int, default=4, help="HIP events around the encode / decode launches on every n-th timed step (the events themselves cost a step 4 us each -- four of them 17 us of 0.29 ms when recorded on every step: --event-every 1)")
+    ap.add_argument("--event-every", type=int, default=1, help="HIP events around the encode / decode launches on every n-th timed step only (measurement aid: recorded around every launch, the four events cost the step ~17 us of 0.29 ms -- value rises by 3-5 %% with n = 4 -- but the sampled launch intervals then come out 1-3 us LONGER, so the default keeps them on every step)")
     ap.add_argument("--record-first", action="store_true", help="index record right behind the encode whose output it reads instead of behind the decode (measured: the CRC kernel gains 4 us from the warm memory-side cache, the decoder and the encoder lose 3 -- the step is the same)")
     ap.add_argument("--sync-decode", action="store_true", help="every frame through the synchronous decode entry (host-parsed header, two synchronisations per frame)")
     ap.add_argument("--no-verify", action="store_true", help="profiling aid for timing-only ablation builds (results are wrong by construction)")
